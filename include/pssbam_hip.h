@@ -1,0 +1,172 @@
+/*
+ * include/pssbam_hip.h -- C ABI of the MI355X (gfx950) tally engine.
+ *
+ * This is the drop-in boundary for pss-bam's per-read hot path.  The reference has no
+ * FFI seam; the loop it replaces is
+ *
+ *     while (fgets(line)) { line2saml(line, sp); process_aln(fwd, rev, genome, sp); }
+ *         /root/reference/pss-bam.c:764-783   (and fragkon.c:342-363 for the k-mer tool)
+ *
+ * i.e. "decode one alignment, filter it, tally it".  A caller now hands *blocks of raw
+ * BAM alignment records* (exactly the bytes between two record boundaries of an
+ * inflated BAM stream) to pssbam_engine_submit*, and collects the same two
+ * unsigned long[(N+2)][16] tables (pss-bam.c:24-35, :755-756) and/or the two k-mer
+ * tables (fragkon.c:335-336) from pssbam_engine_finish.
+ *
+ * Plain C types only.  Every function returns 0 on success and a negative PSSBAM_E*
+ * code on failure; pssbam_last_error() then describes it.  The library never calls
+ * exit() and never falls back to a CPU implementation: without a usable gfx950 device
+ * pssbam_engine_create fails with PSSBAM_ENODEV.
+ *
+ * Threading: an engine is owned by one host thread at a time; different engines
+ * (e.g. one per GPU) are independent.  All work is issued on one HIP stream per engine.
+ */
+#ifndef PSSBAM_HIP_H
+#define PSSBAM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PSSBAM_ABI_VERSION 1
+
+/* error codes */
+#define PSSBAM_OK 0
+#define PSSBAM_EINVAL (-1)   /* bad argument / option outside the supported range        */
+#define PSSBAM_ENODEV (-2)   /* no gfx950 device, or the HIP runtime refused to start    */
+#define PSSBAM_EHIP (-3)     /* a HIP call failed (message has the HIP error string)     */
+#define PSSBAM_ENOMEM (-4)
+#define PSSBAM_ESTATE (-5)   /* call order violated (e.g. submit before set_genome)      */
+#define PSSBAM_EFORMAT (-6)  /* malformed record block                                   */
+
+/* which tallies one pass produces */
+#define PSSBAM_TALLY_PSS 1u   /* substitution tables, pss-bam.c process_aln              */
+#define PSSBAM_TALLY_KMER 2u  /* fragmentation-point k-mers, fragkon.c process_aln       */
+
+/* kernel selection (diagnostics / tests; 0 lets the engine choose) */
+#define PSSBAM_KERNEL_AUTO 0
+#define PSSBAM_KERNEL_SIMPLE 1  /* lane-per-read, global gathers (any N, any k)          */
+#define PSSBAM_KERNEL_TILED 2   /* LDS-staged record tiles, lane=row tally (N <= 30)     */
+
+/* pss-bam's option globals, /root/reference/pss-bam.c:12-18 (set by -r -l -L -q -U -D -m) */
+typedef struct pssbam_pss_opts {
+    int32_t region_len;        /* REGION_LEN, >= 0                                       */
+    uint64_t min_read_len;     /* MIN_READ_LEN                                           */
+    uint64_t max_read_len;     /* MAX_READ_LEN                                           */
+    int32_t min_mq;            /* MIN_MQ (compared unsigned, as the reference does)      */
+    const char *up_ctx;        /* UP_CTX: set of allowed first upstream bases            */
+    const char *down_ctx;      /* DOWN_CTX                                               */
+    int32_t merged_only;       /* MERGED_ONLY                                            */
+} pssbam_pss_opts;
+
+/* fragkon's option globals, /root/reference/fragkon.c:14-18 (set by -k -l -L -q -m) */
+typedef struct pssbam_kmer_opts {
+    int32_t klen;              /* KLEN, 1..12 on the device                              */
+    int32_t min_mq;
+    uint64_t min_read_len;
+    uint64_t max_read_len;
+    int32_t merged_only;
+} pssbam_kmer_opts;
+
+typedef struct pssbam_config {
+    uint32_t abi_version;      /* PSSBAM_ABI_VERSION                                     */
+    uint32_t tally_mask;       /* PSSBAM_TALLY_*                                         */
+    pssbam_pss_opts pss;       /* read when PSSBAM_TALLY_PSS is set                      */
+    pssbam_kmer_opts kmer;     /* read when PSSBAM_TALLY_KMER is set                     */
+    const char *read_group;    /* -R: keep only records with RG:Z:<this>; NULL = all
+                                  (replaces `samtools view -r`, pss-bam.c:150-155)       */
+    int32_t device;            /* HIP device ordinal, -1 = current device                */
+    int32_t kernel;            /* PSSBAM_KERNEL_*                                        */
+} pssbam_config;
+
+typedef struct pssbam_engine pssbam_engine; /* opaque */
+struct genome;                              /* Genome of fasta-genome-io.h               */
+
+/* indices into the stats[] array of pssbam_engine_finish */
+enum {
+    PSSBAM_ST_RECORDS = 0,     /* records submitted                                      */
+    PSSBAM_ST_RG_DROPPED = 1,  /* removed by the -R filter (never reach line2saml)       */
+    PSSBAM_ST_PARSE_SKIP = 2,  /* line2saml would return 1 (SEQ/QUAL length mismatch)    */
+    PSSBAM_ST_NO_CONTIG = 3,   /* find_seq fails: process_aln returns 1                  */
+    PSSBAM_ST_PSS_OK = 4,      /* pss process_aln returns 0                              */
+    PSSBAM_ST_PSS_FILTERED = 5,/* pss process_aln returns -1                             */
+    PSSBAM_ST_KMER_OK = 6,     /* fragkon process_aln returns 0                          */
+    PSSBAM_ST_KMER_FILTERED = 7,/* fragkon process_aln returns 2                         */
+    PSSBAM_ST_KMER_FAIL = 8,   /* fragkon process_aln returns -1 (non-ACGT in a k-mer)   */
+    PSSBAM_ST_N = 16
+};
+
+const char *pssbam_last_error(void);      /* thread-local, never NULL                    */
+int pssbam_device_count(void);            /* number of usable gfx950 devices, 0 if none  */
+
+int pssbam_engine_create(const pssbam_config *cfg, pssbam_engine **out);
+void pssbam_engine_destroy(pssbam_engine *e);
+
+/* Adopt an existing hipStream_t (e.g. torch's current stream) instead of the engine's
+ * own.  Call before any submit. */
+int pssbam_engine_set_stream(pssbam_engine *e, void *hip_stream);
+
+/* Uploads the reference bases (1 byte per base, upper case as loaded, each contig
+ * followed by zero padding) and remembers the sorted id table so contig lookup has
+ * find_seq's strcmp semantics (fasta-genome-io.c:202-219).  The Genome stays owned by
+ * the caller and may be destroyed afterwards. */
+int pssbam_engine_set_genome(pssbam_engine *e, const struct genome *g);
+
+/* Same from plain arrays; when seqs_on_device != 0 the seqs[i] are device pointers
+ * (bench / generators) and are copied device-to-device. */
+int pssbam_engine_set_genome_arrays(pssbam_engine *e, size_t n, const char *const *ids,
+                                    const uint8_t *const *seqs, const uint64_t *lens,
+                                    int seqs_on_device);
+
+/* The BAM header's reference list, in refID order.  Each name is looked up in the
+ * genome exactly like find_seq(genome, RNAME) would be for that record's text form. */
+int pssbam_engine_set_references(pssbam_engine *e, int32_t n_ref, const char *const *names);
+
+/* One block of whole BAM alignment records (each = le32 block_size + block_size
+ * bytes), nbytes < 4 GiB.  offsets[i] is the byte offset of record i's block_size
+ * word, offsets[n_records] == nbytes.  Host memory; the engine has copied what it
+ * needs when the call returns (the copy and the kernel run asynchronously). */
+int pssbam_engine_submit(pssbam_engine *e, const void *records, uint64_t nbytes,
+                         const uint32_t *offsets, uint32_t n_records);
+
+/* Same with both arrays already resident in device memory; nothing is copied and the
+ * buffers must stay valid until pssbam_engine_sync / finish. */
+int pssbam_engine_submit_device(pssbam_engine *e, const void *d_records, uint64_t nbytes,
+                                const uint32_t *d_offsets, uint32_t n_records);
+
+int pssbam_engine_sync(pssbam_engine *e);
+
+/* Drains the stream and copies the accumulated tables out.  Any pointer may be NULL.
+ *   fwd, rev : (region_len+2)*16 each; row 0/1 = 2nd/1st context base, row 2+i = position i
+ *   k5, k3   : 4^klen each (64-bit; the fragkon front end clamps to UINT_MAX on print,
+ *              kmer.c:102-104)
+ * Tables keep accumulating across calls until pssbam_engine_reset. */
+int pssbam_engine_finish(pssbam_engine *e, unsigned long *fwd, unsigned long *rev, uint64_t *k5,
+                         uint64_t *k3, uint64_t stats[PSSBAM_ST_N]);
+int pssbam_engine_reset(pssbam_engine *e);
+
+/* The device-resident counter block [fwd | rev | k5 | k3 | stats] as one array of
+ * n_u64 64-bit words, for a caller-side RCCL reduce across GPUs (sum, uint64). */
+int pssbam_engine_counters_device(pssbam_engine *e, void **d_counters, size_t *n_u64);
+
+/* HIP-event stopwatch on the engine's stream: begin records an event, end records a
+ * second one, waits for it and returns the elapsed device time in milliseconds. */
+int pssbam_engine_timer_begin(pssbam_engine *e);
+int pssbam_engine_timer_end(pssbam_engine *e, float *ms);
+/* Sum of the tally kernels' own durations (event pair around every launch) and their
+ * number since the last call with reset != 0. */
+int pssbam_engine_kernel_time(pssbam_engine *e, double *total_ms, uint64_t *n_launches, int reset);
+
+/* Host helper: walks the block_size chain of an inflated BAM record stream.  Writes up
+ * to max_records offsets (+ the end sentinel), returns the number of whole records
+ * found (>= 0) or PSSBAM_EFORMAT; *consumed = bytes covered by those records. */
+int64_t pssbam_index_records(const void *bytes, uint64_t nbytes, uint32_t *offsets,
+                             uint64_t max_records, uint64_t *consumed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PSSBAM_HIP_H */

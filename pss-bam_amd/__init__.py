@@ -1,0 +1,249 @@
+"""ctypes face of the MI355X tally engine (libpssbam_hip.so, include/pssbam_hip.h).
+
+This module is thin plumbing for tests/, bench.py and __graft_entry__: it loads the
+C-ABI shared library and marshals arguments.  There is no computation here and no CPU
+fallback: if the library (or a gfx950 device) is missing, construction raises.
+
+The directory name contains a hyphen, so import it through `load_pkg()` in
+__graft_entry__.py (importlib by path) under the module name `pss_bam_amd`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import subprocess
+from dataclasses import dataclass
+from pathlib import Path
+
+import numpy as np
+
+PKG_DIR = Path(__file__).resolve().parent
+ROOT = PKG_DIR.parent
+LIB_HIP = PKG_DIR / "libpssbam_hip.so"
+LIB_HOST = PKG_DIR / "libpssbam_host.so"
+LIB_SYNTH = PKG_DIR / "libpssbam_synth.so"
+
+TALLY_PSS, TALLY_KMER = 1, 2
+KERNEL_AUTO, KERNEL_SIMPLE, KERNEL_TILED = 0, 1, 2
+ST_NAMES = ["records", "rg_dropped", "parse_skip", "no_contig", "pss_ok", "pss_filtered", "kmer_ok",
+            "kmer_filtered", "kmer_fail"]
+ST_N = 16
+
+# every symbol include/pssbam_hip.h declares (checked by tests/test_cabi.py)
+HIP_SYMBOLS = [
+    "pssbam_last_error", "pssbam_device_count", "pssbam_engine_create", "pssbam_engine_destroy",
+    "pssbam_engine_set_stream", "pssbam_engine_set_genome", "pssbam_engine_set_genome_arrays",
+    "pssbam_engine_set_references", "pssbam_engine_submit", "pssbam_engine_submit_device", "pssbam_engine_sync",
+    "pssbam_engine_finish", "pssbam_engine_reset", "pssbam_engine_counters_device", "pssbam_engine_timer_begin",
+    "pssbam_engine_timer_end", "pssbam_engine_kernel_time", "pssbam_index_records",
+]
+
+
+def build(verbose: bool = False) -> None:
+    """make -C pss-bam_amd: compiles every HIP extension for gfx950 plus the host C side."""
+    subprocess.run(["make", "-C", str(PKG_DIR), "all"], check=True,
+                   stdout=None if verbose else subprocess.DEVNULL)
+
+
+class PssbamError(RuntimeError):
+    pass
+
+
+class _PssOpts(C.Structure):
+    _fields_ = [("region_len", C.c_int32), ("min_read_len", C.c_uint64), ("max_read_len", C.c_uint64),
+                ("min_mq", C.c_int32), ("up_ctx", C.c_char_p), ("down_ctx", C.c_char_p),
+                ("merged_only", C.c_int32)]
+
+
+class _KmerOpts(C.Structure):
+    _fields_ = [("klen", C.c_int32), ("min_mq", C.c_int32), ("min_read_len", C.c_uint64),
+                ("max_read_len", C.c_uint64), ("merged_only", C.c_int32)]
+
+
+class _Config(C.Structure):
+    _fields_ = [("abi_version", C.c_uint32), ("tally_mask", C.c_uint32), ("pss", _PssOpts), ("kmer", _KmerOpts),
+                ("read_group", C.c_char_p), ("device", C.c_int32), ("kernel", C.c_int32)]
+
+
+_hip = None
+
+
+def hip_lib() -> C.CDLL:
+    """Loads libpssbam_hip.so; raises (loudly) when it has not been built."""
+    global _hip
+    if _hip is not None:
+        return _hip
+    if not LIB_HIP.exists():
+        raise PssbamError(f"{LIB_HIP} is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950)")
+    L = C.CDLL(str(LIB_HIP))
+    L.pssbam_last_error.restype = C.c_char_p
+    L.pssbam_engine_create.argtypes = [C.POINTER(_Config), C.POINTER(C.c_void_p)]
+    L.pssbam_engine_destroy.argtypes = [C.c_void_p]
+    L.pssbam_engine_destroy.restype = None
+    L.pssbam_engine_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    L.pssbam_engine_set_genome.argtypes = [C.c_void_p, C.c_void_p]
+    L.pssbam_engine_set_genome_arrays.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_char_p),
+                                                  C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.c_int]
+    L.pssbam_engine_set_references.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_char_p)]
+    L.pssbam_engine_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32]
+    L.pssbam_engine_submit_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32]
+    L.pssbam_engine_sync.argtypes = [C.c_void_p]
+    L.pssbam_engine_finish.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.pssbam_engine_reset.argtypes = [C.c_void_p]
+    L.pssbam_engine_counters_device.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    L.pssbam_engine_timer_begin.argtypes = [C.c_void_p]
+    L.pssbam_engine_timer_end.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+    L.pssbam_engine_kernel_time.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]
+    L.pssbam_index_records.restype = C.c_int64
+    L.pssbam_index_records.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+    _hip = L
+    return L
+
+
+def _chk(rc: int) -> None:
+    if rc != 0:
+        raise PssbamError(f"pssbam error {rc}: {hip_lib().pssbam_last_error().decode()}")
+
+
+def index_records(buf: np.ndarray) -> np.ndarray:
+    """offsets (n+1,) u32 of the whole records in an inflated BAM record stream"""
+    L = hip_lib()
+    n = L.pssbam_index_records(buf.ctypes.data, buf.size, None, 1 << 62, None)
+    if n < 0:
+        _chk(int(n))
+    offs = np.empty(n + 1, dtype=np.uint32)
+    consumed = C.c_uint64()
+    n2 = L.pssbam_index_records(buf.ctypes.data, buf.size, offs.ctypes.data, n, C.byref(consumed))
+    assert n2 == n
+    return offs
+
+
+@dataclass
+class Tables:
+    fwd: np.ndarray | None
+    rev: np.ndarray | None
+    k5: np.ndarray | None
+    k3: np.ndarray | None
+    stats: dict
+
+
+class Engine:
+    """One engine = one GPU, one stream.  Options mirror the two reference CLIs:
+    `pss` = dict(region_len, min_read_len, max_read_len, min_mq, up_ctx, down_ctx, merged_only),
+    `kmer` = dict(klen, min_mq, min_read_len, max_read_len, merged_only)."""
+
+    def __init__(self, pss: dict | None = None, kmer: dict | None = None, read_group: str | None = None,
+                 kernel: int = KERNEL_AUTO, device: int = -1):
+        L = hip_lib()
+        cfg = _Config()
+        cfg.abi_version = 1
+        cfg.tally_mask = (TALLY_PSS if pss is not None else 0) | (TALLY_KMER if kmer is not None else 0)
+        self._keep = []
+        if pss is not None:
+            up, dn = pss.get("up_ctx", "ACGT").encode(), pss.get("down_ctx", "ACGT").encode()
+            self._keep += [up, dn]
+            cfg.pss = _PssOpts(pss.get("region_len", 15), pss.get("min_read_len", 0),
+                               pss.get("max_read_len", 250000000), pss.get("min_mq", 0), up, dn,
+                               int(pss.get("merged_only", False)))
+            self.region_len = cfg.pss.region_len
+        if kmer is not None:
+            cfg.kmer = _KmerOpts(kmer.get("klen", 8), kmer.get("min_mq", 0), kmer.get("min_read_len", 0),
+                                 kmer.get("max_read_len", 250000000), int(kmer.get("merged_only", False)))
+            self.klen = cfg.kmer.klen
+        self.has_pss, self.has_kmer = pss is not None, kmer is not None
+        if read_group is not None:
+            rg = read_group.encode()
+            self._keep.append(rg)
+            cfg.read_group = rg
+        cfg.device = device
+        cfg.kernel = kernel
+        h = C.c_void_p()
+        _chk(L.pssbam_engine_create(C.byref(cfg), C.byref(h)))
+        self._h = h
+        self._L = L
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.pssbam_engine_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def set_stream(self, hip_stream: int):
+        _chk(self._L.pssbam_engine_set_stream(self._h, C.c_void_p(hip_stream)))
+
+    def set_genome_arrays(self, contigs: list[tuple[str, np.ndarray]]):
+        """contigs: [(id, uint8 array in loaded form)] (host memory)"""
+        n = len(contigs)
+        arrs = [np.ascontiguousarray(a, dtype=np.uint8) for _, a in contigs]
+        ids = (C.c_char_p * n)(*[c[0].encode() for c in contigs])
+        seqs = (C.c_void_p * n)(*[a.ctypes.data for a in arrs])
+        lens = (C.c_uint64 * n)(*[a.size for a in arrs])
+        _chk(self._L.pssbam_engine_set_genome_arrays(self._h, n, ids, seqs, lens, 0))
+
+    def set_genome_device(self, contigs: list[tuple[str, int, int]]):
+        """contigs: [(id, device_ptr, length)]"""
+        n = len(contigs)
+        ids = (C.c_char_p * n)(*[c[0].encode() for c in contigs])
+        seqs = (C.c_void_p * n)(*[c[1] for c in contigs])
+        lens = (C.c_uint64 * n)(*[c[2] for c in contigs])
+        _chk(self._L.pssbam_engine_set_genome_arrays(self._h, n, ids, seqs, lens, 1))
+
+    def set_genome_struct(self, genome_ptr: int):
+        """genome_ptr: a Genome* from init_genome (libpssbam_host.so)"""
+        _chk(self._L.pssbam_engine_set_genome(self._h, C.c_void_p(genome_ptr)))
+
+    def set_references(self, names: list[str]):
+        n = len(names)
+        arr = (C.c_char_p * max(n, 1))(*[s.encode() for s in names])
+        _chk(self._L.pssbam_engine_set_references(self._h, n, arr))
+
+    def submit(self, records: np.ndarray, offsets: np.ndarray | None = None):
+        records = np.ascontiguousarray(records, dtype=np.uint8)
+        if offsets is None:
+            offsets = index_records(records)
+            if int(offsets[-1]) != records.size:
+                raise PssbamError("record block ends in a partial record")
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint32)
+        _chk(self._L.pssbam_engine_submit(self._h, records.ctypes.data, records.size, offsets.ctypes.data,
+                                          offsets.size - 1))
+
+    def submit_device(self, d_records: int, nbytes: int, d_offsets: int, n_records: int):
+        _chk(self._L.pssbam_engine_submit_device(self._h, C.c_void_p(d_records), nbytes, C.c_void_p(d_offsets),
+                                                 n_records))
+
+    def sync(self):
+        _chk(self._L.pssbam_engine_sync(self._h))
+
+    def reset(self):
+        _chk(self._L.pssbam_engine_reset(self._h))
+
+    def finish(self) -> Tables:
+        fwd = rev = k5 = k3 = None
+        if self.has_pss:
+            fwd = np.zeros((self.region_len + 2, 16), dtype=np.uint64)
+            rev = np.zeros_like(fwd)
+        if self.has_kmer:
+            k5 = np.zeros(4 ** self.klen, dtype=np.uint64)
+            k3 = np.zeros_like(k5)
+        st = np.zeros(ST_N, dtype=np.uint64)
+        p = lambda a: a.ctypes.data if a is not None else None  # noqa: E731
+        _chk(self._L.pssbam_engine_finish(self._h, p(fwd), p(rev), p(k5), p(k3), st.ctypes.data))
+        return Tables(fwd, rev, k5, k3, {n: int(st[i]) for i, n in enumerate(ST_NAMES)})
+
+    def counters_device(self) -> tuple[int, int]:
+        ptr, n = C.c_void_p(), C.c_size_t()
+        _chk(self._L.pssbam_engine_counters_device(self._h, C.byref(ptr), C.byref(n)))
+        return int(ptr.value), int(n.value)
+
+    def timer_begin(self):
+        _chk(self._L.pssbam_engine_timer_begin(self._h))
+
+    def timer_end(self) -> float:
+        ms = C.c_float()
+        _chk(self._L.pssbam_engine_timer_end(self._h, C.byref(ms)))
+        return float(ms.value)
+
+    def kernel_time(self, reset: bool = True) -> tuple[float, int]:
+        ms, n = C.c_double(), C.c_uint64()
+        _chk(self._L.pssbam_engine_kernel_time(self._h, C.byref(ms), C.byref(n), int(reset)))
+        return float(ms.value), int(n.value)

@@ -1,0 +1,595 @@
+// pss-bam_amd/csrc/engine.hip -- the C ABI declared in include/pssbam_hip.h.
+//
+// Host side of the MI355X tally engine: device-resident genome, BAM refID -> contig map
+// with find_seq semantics, double-buffered H2D staging of record blocks, kernel choice
+// and launch geometry, u64 counter block.  Written for gfx950 only; there is no CPU path.
+#include "../../include/pssbam_hip.h"
+#include "../../include/fasta-genome-io.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "tally_kernels.h"
+
+using namespace pssbam;
+
+// --------------------------------------------------------------------------------------
+// errors
+// --------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess)                                                                  \
+            return fail(PSSBAM_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+extern "C" const char *pssbam_last_error(void) { return g_err; }
+
+static bool device_is_gfx950(int dev) {
+    hipDeviceProp_t pr;
+    if (hipGetDeviceProperties(&pr, dev) != hipSuccess) return false;
+    return strncmp(pr.gcnArchName, "gfx950", 6) == 0;
+}
+
+extern "C" int pssbam_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    int ok = 0;
+    for (int d = 0; d < n; d++) ok += device_is_gfx950(d) ? 1 : 0;
+    return ok;
+}
+
+// --------------------------------------------------------------------------------------
+// engine
+// --------------------------------------------------------------------------------------
+struct Slot {  // one in-flight host-submitted block
+    uint8_t *d_recs = nullptr;
+    size_t recs_cap = 0;
+    uint32_t *d_offs = nullptr;
+    size_t offs_cap = 0;  // entries
+    hipEvent_t copied = nullptr, consumed = nullptr;
+    bool busy = false;
+};
+
+struct pssbam_engine {
+    pssbam_config cfg{};
+    std::string up_ctx, down_ctx, rg;
+    bool has_rg = false;
+    int device = 0;
+    int n_cu = 0;
+    hipStream_t stream = nullptr, copy_stream = nullptr;
+    bool own_stream = false;
+
+    // genome
+    uint8_t *d_genome = nullptr;
+    uint64_t genome_bytes = 0;
+    uint64_t *d_contig_start = nullptr, *d_contig_len = nullptr;
+    std::vector<std::string> contig_ids;  // sorted by strcmp, like Genome.seqs
+    int32_t star_contig = -1;
+    // references
+    int32_t *d_ref_map = nullptr;
+    int32_t n_ref = 0;
+    bool have_refs = false;
+    // -R
+    uint8_t *d_rg = nullptr;
+    // counters
+    unsigned long long *d_counters = nullptr;
+    size_t n_counters = 0;
+    uint32_t rows = 0, off_rev = 0, off_k5 = 0, off_k3 = 0, off_stats = 0;
+    uint64_t n_bins = 0;
+    // staging
+    Slot slots[2];
+    int next_slot = 0;
+    // timing
+    hipEvent_t t_begin = nullptr, t_end = nullptr;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> launch_events;
+    std::vector<hipEvent_t> event_pool;
+    double kernel_ms = 0.0;
+    uint64_t kernel_launches = 0;
+    // tuning overrides (environment, for experiments)
+    int env_tile_reads = 0, env_tile_cap = 0, env_grid_mult = 0, env_simple_blocks = 0;
+};
+
+static void ctx_mask(const char *set, uint32_t (&m)[8]) {
+    // strchr(set, c) != NULL: every byte of the string, plus the terminator itself
+    memset(m, 0, sizeof m);
+    for (const unsigned char *p = (const unsigned char *)set;; p++) {
+        m[*p >> 5] |= 1u << (*p & 31);
+        if (!*p) break;
+    }
+}
+
+static int env_int(const char *name) {
+    const char *v = getenv(name);
+    return v ? atoi(v) : 0;
+}
+
+extern "C" int pssbam_engine_create(const pssbam_config *cfg, pssbam_engine **out) {
+    if (!cfg || !out) return fail(PSSBAM_EINVAL, "null argument");
+    *out = nullptr;
+    if (cfg->abi_version != PSSBAM_ABI_VERSION)
+        return fail(PSSBAM_EINVAL, "abi_version %u != %u", cfg->abi_version, PSSBAM_ABI_VERSION);
+    if (!(cfg->tally_mask & (PSSBAM_TALLY_PSS | PSSBAM_TALLY_KMER)) ||
+        (cfg->tally_mask & ~(PSSBAM_TALLY_PSS | PSSBAM_TALLY_KMER)))
+        return fail(PSSBAM_EINVAL, "tally_mask must be a non-empty subset of PSS|KMER");
+    if ((cfg->tally_mask & PSSBAM_TALLY_PSS)) {
+        if (cfg->pss.region_len < 0 || cfg->pss.region_len > 1000000)
+            return fail(PSSBAM_EINVAL, "region_len %d out of range", cfg->pss.region_len);
+        if (!cfg->pss.up_ctx || !cfg->pss.down_ctx) return fail(PSSBAM_EINVAL, "up_ctx/down_ctx must be set");
+    }
+    if ((cfg->tally_mask & PSSBAM_TALLY_KMER) && (cfg->kmer.klen < 1 || cfg->kmer.klen > 12))
+        return fail(PSSBAM_EINVAL, "klen %d outside the device range 1..12", cfg->kmer.klen);
+
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0)
+        return fail(PSSBAM_ENODEV, "no HIP device available (this engine has no CPU path)");
+    int dev = cfg->device;
+    if (dev < 0) HIP_TRY(hipGetDevice(&dev));
+    if (dev >= n_dev) return fail(PSSBAM_ENODEV, "device %d does not exist (%d present)", dev, n_dev);
+    if (!device_is_gfx950(dev) && !getenv("PSSBAM_ALLOW_OTHER_ARCH"))
+        return fail(PSSBAM_ENODEV, "device %d is not gfx950", dev);
+    HIP_TRY(hipSetDevice(dev));
+
+    pssbam_engine *e = new pssbam_engine();
+    e->cfg = *cfg;
+    e->device = dev;
+    if (cfg->tally_mask & PSSBAM_TALLY_PSS) {
+        e->up_ctx = cfg->pss.up_ctx;
+        e->down_ctx = cfg->pss.down_ctx;
+    }
+    if (cfg->read_group) {
+        e->rg = cfg->read_group;
+        e->has_rg = true;
+    }
+    e->cfg.pss.up_ctx = e->cfg.pss.down_ctx = e->cfg.read_group = nullptr;
+    hipDeviceProp_t pr;
+    HIP_TRY(hipGetDeviceProperties(&pr, dev));
+    e->n_cu = pr.multiProcessorCount;
+    HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+    e->own_stream = true;
+    HIP_TRY(hipEventCreate(&e->t_begin));
+    HIP_TRY(hipEventCreate(&e->t_end));
+
+    e->rows = (cfg->tally_mask & PSSBAM_TALLY_PSS) ? (uint32_t)cfg->pss.region_len + 2u : 0u;
+    e->n_bins = (cfg->tally_mask & PSSBAM_TALLY_KMER) ? (1ull << (2 * cfg->kmer.klen)) : 0ull;
+    e->off_rev = e->rows * 16u;
+    e->off_k5 = 2u * e->rows * 16u;
+    e->off_k3 = (uint32_t)(e->off_k5 + e->n_bins);
+    e->off_stats = (uint32_t)(e->off_k3 + e->n_bins);
+    e->n_counters = (size_t)e->off_stats + PSSBAM_ST_N;
+    HIP_TRY(hipMalloc(&e->d_counters, e->n_counters * sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(e->d_counters, 0, e->n_counters * sizeof(unsigned long long), e->stream));
+    if (e->has_rg) {
+        HIP_TRY(hipMalloc(&e->d_rg, e->rg.size() + 16));
+        HIP_TRY(hipMemcpy(e->d_rg, e->rg.data(), e->rg.size(), hipMemcpyHostToDevice));
+    }
+    for (Slot &s : e->slots) {
+        HIP_TRY(hipEventCreateWithFlags(&s.copied, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&s.consumed, hipEventDisableTiming));
+    }
+    e->env_tile_reads = env_int("PSSBAM_TILE_READS");
+    e->env_tile_cap = env_int("PSSBAM_TILE_CAP");
+    e->env_grid_mult = env_int("PSSBAM_GRID_MULT");
+    e->env_simple_blocks = env_int("PSSBAM_SIMPLE_BLOCKS");
+    *out = e;
+    return PSSBAM_OK;
+}
+
+extern "C" void pssbam_engine_destroy(pssbam_engine *e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    if (e->copy_stream) (void)hipStreamSynchronize(e->copy_stream);
+    for (Slot &s : e->slots) {
+        if (s.d_recs) (void)hipFree(s.d_recs);
+        if (s.d_offs) (void)hipFree(s.d_offs);
+        if (s.copied) (void)hipEventDestroy(s.copied);
+        if (s.consumed) (void)hipEventDestroy(s.consumed);
+    }
+    for (auto &p : e->launch_events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    for (hipEvent_t ev : e->event_pool) (void)hipEventDestroy(ev);
+    if (e->t_begin) (void)hipEventDestroy(e->t_begin);
+    if (e->t_end) (void)hipEventDestroy(e->t_end);
+    if (e->d_genome) (void)hipFree(e->d_genome);
+    if (e->d_contig_start) (void)hipFree(e->d_contig_start);
+    if (e->d_contig_len) (void)hipFree(e->d_contig_len);
+    if (e->d_ref_map) (void)hipFree(e->d_ref_map);
+    if (e->d_rg) (void)hipFree(e->d_rg);
+    if (e->d_counters) (void)hipFree(e->d_counters);
+    if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
+    if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
+    delete e;
+}
+
+extern "C" int pssbam_engine_set_stream(pssbam_engine *e, void *hip_stream) {
+    if (!e) return fail(PSSBAM_EINVAL, "null engine");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (e->own_stream) HIP_TRY(hipStreamDestroy(e->stream));
+    e->stream = (hipStream_t)hip_stream;
+    e->own_stream = false;
+    return PSSBAM_OK;
+}
+
+// --------------------------------------------------------------------------------------
+// genome + references
+// --------------------------------------------------------------------------------------
+static constexpr uint64_t CONTIG_ALIGN = 256, CONTIG_PAD = 256;
+
+extern "C" int pssbam_engine_set_genome_arrays(pssbam_engine *e, size_t n, const char *const *ids,
+                                               const uint8_t *const *seqs, const uint64_t *lens,
+                                               int seqs_on_device) {
+    if (!e || (n && (!ids || !seqs || !lens))) return fail(PSSBAM_EINVAL, "null argument");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    // sorted view, as init_genome leaves Genome.seqs (fasta-genome-io.c:236)
+    std::vector<size_t> order(n);
+    for (size_t i = 0; i < n; i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return strcmp(ids[a], ids[b]) < 0; });
+    std::vector<uint64_t> start(n), len(n);
+    uint64_t total = CONTIG_PAD;
+    for (size_t k = 0; k < n; k++) {
+        start[k] = total;
+        len[k] = lens[order[k]];
+        total += (len[k] + CONTIG_PAD + CONTIG_ALIGN - 1) / CONTIG_ALIGN * CONTIG_ALIGN;
+    }
+    if (e->d_genome) { HIP_TRY(hipFree(e->d_genome)); e->d_genome = nullptr; }
+    if (e->d_contig_start) { HIP_TRY(hipFree(e->d_contig_start)); e->d_contig_start = nullptr; }
+    if (e->d_contig_len) { HIP_TRY(hipFree(e->d_contig_len)); e->d_contig_len = nullptr; }
+    HIP_TRY(hipMalloc(&e->d_genome, total));
+    HIP_TRY(hipMemsetAsync(e->d_genome, 0, total, e->stream));
+    for (size_t k = 0; k < n; k++) {
+        if (!len[k]) continue;
+        HIP_TRY(hipMemcpyAsync(e->d_genome + start[k], seqs[order[k]], len[k],
+                               seqs_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, e->stream));
+    }
+    hipLaunchKernelGGL(upcase_kernel, dim3(2048), dim3(256), 0, e->stream, e->d_genome, total);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMalloc(&e->d_contig_start, (n + 1) * sizeof(uint64_t)));
+    HIP_TRY(hipMalloc(&e->d_contig_len, (n + 1) * sizeof(uint64_t)));
+    HIP_TRY(hipMemcpyAsync(e->d_contig_start, start.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->d_contig_len, len.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    e->genome_bytes = total;
+    e->contig_ids.clear();
+    for (size_t k = 0; k < n; k++) e->contig_ids.emplace_back(ids[order[k]]);
+    e->star_contig = -1;
+    e->have_refs = false;
+    {   // RNAME "*" (refID -1) goes through find_seq like any other name
+        auto it = std::lower_bound(e->contig_ids.begin(), e->contig_ids.end(), std::string("*"),
+                                   [](const std::string &a, const std::string &b) { return strcmp(a.c_str(), b.c_str()) < 0; });
+        if (it != e->contig_ids.end() && *it == "*") e->star_contig = (int32_t)(it - e->contig_ids.begin());
+    }
+    return PSSBAM_OK;
+}
+
+extern "C" int pssbam_engine_set_genome(pssbam_engine *e, const struct genome *g) {
+    if (!e || !g) return fail(PSSBAM_EINVAL, "null argument");
+    std::vector<const char *> ids(g->n_seqs);
+    std::vector<const uint8_t *> seqs(g->n_seqs);
+    std::vector<uint64_t> lens(g->n_seqs);
+    for (size_t i = 0; i < g->n_seqs; i++) {
+        ids[i] = g->seqs[i]->id;
+        seqs[i] = (const uint8_t *)g->seqs[i]->seq;
+        lens[i] = g->seqs[i]->len;
+    }
+    return pssbam_engine_set_genome_arrays(e, g->n_seqs, ids.data(), seqs.data(), lens.data(), 0);
+}
+
+extern "C" int pssbam_engine_set_references(pssbam_engine *e, int32_t n_ref, const char *const *names) {
+    if (!e || n_ref < 0 || (n_ref && !names)) return fail(PSSBAM_EINVAL, "bad argument");
+    if (!e->d_genome) return fail(PSSBAM_ESTATE, "set_genome must precede set_references");
+    HIP_TRY(hipSetDevice(e->device));
+    std::vector<int32_t> map((size_t)n_ref + 1, -1);
+    for (int32_t i = 0; i < n_ref; i++) {
+        // bsearch with strcmp over the sorted ids == find_seq (fasta-genome-io.c:202-213)
+        size_t lo = 0, hi = e->contig_ids.size();
+        while (lo < hi) {
+            const size_t mid = (lo + hi) / 2;
+            const int c = strcmp(names[i], e->contig_ids[mid].c_str());
+            if (c == 0) { map[i] = (int32_t)mid; break; }
+            if (c < 0) hi = mid; else lo = mid + 1;
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (e->d_ref_map) { HIP_TRY(hipFree(e->d_ref_map)); e->d_ref_map = nullptr; }
+    HIP_TRY(hipMalloc(&e->d_ref_map, ((size_t)n_ref + 1) * sizeof(int32_t)));
+    HIP_TRY(hipMemcpy(e->d_ref_map, map.data(), ((size_t)n_ref + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
+    e->n_ref = n_ref;
+    e->have_refs = true;
+    return PSSBAM_OK;
+}
+
+// --------------------------------------------------------------------------------------
+// launch
+// --------------------------------------------------------------------------------------
+static hipEvent_t take_event(pssbam_engine *e) {
+    if (!e->event_pool.empty()) {
+        hipEvent_t ev = e->event_pool.back();
+        e->event_pool.pop_back();
+        return ev;
+    }
+    hipEvent_t ev = nullptr;
+    (void)hipEventCreate(&ev);
+    return ev;
+}
+
+static int resolve_launch_events(pssbam_engine *e) {
+    for (auto &p : e->launch_events) {
+        float ms = 0.f;
+        HIP_TRY(hipEventSynchronize(p.second));
+        HIP_TRY(hipEventElapsedTime(&ms, p.first, p.second));
+        e->kernel_ms += ms;
+        e->kernel_launches++;
+        e->event_pool.push_back(p.first);
+        e->event_pool.push_back(p.second);
+    }
+    e->launch_events.clear();
+    return PSSBAM_OK;
+}
+
+template <class K>
+static int prep_kernel(K kernel, uint32_t lds_bytes, int *occ) {
+    HIP_TRY(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(occ, kernel, TILED_THREADS, lds_bytes));
+    if (*occ < 1) return fail(PSSBAM_EHIP, "kernel does not fit a CU with %u bytes of LDS", lds_bytes);
+    return PSSBAM_OK;
+}
+
+static int launch_tally(pssbam_engine *e, const uint8_t *d_recs, uint64_t nbytes, const uint32_t *d_offs,
+                        uint32_t n_records) {
+    if (!n_records) return PSSBAM_OK;
+    const pssbam_config &c = e->cfg;
+    TallyParams P{};
+    P.recs = d_recs;
+    P.offs = d_offs;
+    P.n_recs = n_records;
+    P.tally_mask = c.tally_mask;
+    P.genome = e->d_genome;
+    P.contig_start = e->d_contig_start;
+    P.contig_len = e->d_contig_len;
+    P.ref_map = e->d_ref_map;
+    P.n_ref = e->n_ref;
+    P.star_contig = e->star_contig;
+    const bool do_pss = (c.tally_mask & PSSBAM_TALLY_PSS) != 0, do_kmer = (c.tally_mask & PSSBAM_TALLY_KMER) != 0;
+    if (do_pss) {
+        P.N = c.pss.region_len;
+        P.pss_min_mq = (uint32_t)c.pss.min_mq;
+        P.pss_min_len = c.pss.min_read_len;
+        P.pss_max_len = c.pss.max_read_len;
+        P.pss_merged_only = c.pss.merged_only ? 1u : 0u;
+        ctx_mask(e->up_ctx.c_str(), P.up_mask);
+        ctx_mask(e->down_ctx.c_str(), P.down_mask);
+    }
+    if (do_kmer) {
+        P.K = c.kmer.klen;
+        P.fk_min_mq = (uint32_t)c.kmer.min_mq;
+        P.fk_min_len = c.kmer.min_read_len;
+        P.fk_max_len = c.kmer.max_read_len;
+        P.fk_merged_only = c.kmer.merged_only ? 1u : 0u;
+    }
+    P.rg = e->has_rg ? e->d_rg : nullptr;
+    P.rg_len = (uint32_t)e->rg.size();
+    P.counters = e->d_counters;
+    P.off_rev = e->off_rev;
+    P.off_k5 = e->off_k5;
+    P.off_k3 = e->off_k3;
+    P.off_stats = e->off_stats;
+
+    int kernel = c.kernel;
+    if (kernel == PSSBAM_KERNEL_AUTO)
+        kernel = (do_pss && c.pss.region_len > TILED_MAX_N) ? PSSBAM_KERNEL_SIMPLE : PSSBAM_KERNEL_TILED;
+    if (kernel == PSSBAM_KERNEL_TILED && do_pss && c.pss.region_len > TILED_MAX_N)
+        return fail(PSSBAM_EINVAL, "tiled kernel supports region_len <= %d", TILED_MAX_N);
+
+    hipEvent_t ev0 = take_event(e), ev1 = take_event(e);
+    if (!ev0 || !ev1) return fail(PSSBAM_EHIP, "hipEventCreate failed");
+    HIP_TRY(hipEventRecord(ev0, e->stream));
+
+    if (kernel == PSSBAM_KERNEL_SIMPLE) {
+        const uint32_t tab_bytes = do_pss ? 2u * e->rows * 16u * 4u : 0u;
+        const bool lds_tab = do_pss && tab_bytes <= 60u * 1024u;
+        uint32_t blocks = (uint32_t)std::min<uint64_t>(((uint64_t)n_records + 255) / 256, (uint64_t)e->n_cu * 8);
+        if (e->env_simple_blocks > 0) blocks = (uint32_t)e->env_simple_blocks;
+        if (lds_tab) hipLaunchKernelGGL(tally_simple<true>, dim3(blocks), dim3(256), tab_bytes, e->stream, P);
+        else hipLaunchKernelGGL(tally_simple<false>, dim3(blocks), dim3(256), 0, e->stream, P);
+    } else {
+        // tile geometry from the block's mean record size; records that overflow the
+        // staging window are handled (slowly, correctly) straight from global memory
+        const uint64_t avg = std::max<uint64_t>(40, nbytes / n_records);
+        uint32_t T = avg * 256 <= 36 * 1024 ? 256u : avg * 128 <= 40 * 1024 ? 128u : 64u;
+        if (e->env_tile_reads > 0) T = (uint32_t)e->env_tile_reads;
+        uint64_t cap64 = (uint64_t)T * avg + (uint64_t)T * avg / 8 + 256;
+        cap64 = std::min<uint64_t>(cap64, 96 * 1024);
+        if (e->env_tile_cap > 0) cap64 = (uint64_t)e->env_tile_cap;
+        P.reads_per_tile = T;
+        P.tile_bytes_cap = (uint32_t)((cap64 + 15) & ~15ull);
+        const bool kmer_lds = do_kmer && c.kmer.klen <= KMER_LDS_MAX_K;
+        const uint32_t lds = tiled_lds_bytes(T, P.tile_bytes_cap, kmer_lds, c.kmer.klen);
+        const uint32_t n_tiles = (n_records + T - 1) / T;
+        int occ = 0, rc = PSSBAM_OK;
+        const int mult = e->env_grid_mult > 0 ? e->env_grid_mult : 1;
+#define LAUNCH_TILED(PSS, KM, LK)                                                                  \
+    do {                                                                                           \
+        rc = prep_kernel(tally_tiled<PSS, KM, LK>, lds, &occ);                                     \
+        if (rc == PSSBAM_OK) {                                                                     \
+            const uint32_t grid = (uint32_t)std::min<uint64_t>(n_tiles, (uint64_t)e->n_cu * occ * mult); \
+            hipLaunchKernelGGL((tally_tiled<PSS, KM, LK>), dim3(grid), dim3(TILED_THREADS), lds, e->stream, P); \
+        }                                                                                          \
+    } while (0)
+        if (do_pss && do_kmer) { if (kmer_lds) LAUNCH_TILED(true, true, true); else LAUNCH_TILED(true, true, false); }
+        else if (do_pss) LAUNCH_TILED(true, false, false);
+        else { if (kmer_lds) LAUNCH_TILED(false, true, true); else LAUNCH_TILED(false, true, false); }
+#undef LAUNCH_TILED
+        if (rc != PSSBAM_OK) return rc;
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ev1, e->stream));
+    e->launch_events.emplace_back(ev0, ev1);
+    if (e->launch_events.size() > 4096) return resolve_launch_events(e);
+    return PSSBAM_OK;
+}
+
+static int check_ready(pssbam_engine *e) {
+    if (!e) return fail(PSSBAM_EINVAL, "null engine");
+    if (!e->d_genome) return fail(PSSBAM_ESTATE, "set_genome has not been called");
+    if (!e->have_refs) return fail(PSSBAM_ESTATE, "set_references has not been called");
+    return PSSBAM_OK;
+}
+
+extern "C" int pssbam_engine_submit_device(pssbam_engine *e, const void *d_records, uint64_t nbytes,
+                                           const uint32_t *d_offsets, uint32_t n_records) {
+    int rc = check_ready(e);
+    if (rc) return rc;
+    if (n_records && (!d_records || !d_offsets)) return fail(PSSBAM_EINVAL, "null buffer");
+    if (nbytes >= (1ull << 32)) return fail(PSSBAM_EINVAL, "record block must be < 4 GiB (got %llu)", (unsigned long long)nbytes);
+    if (((uintptr_t)d_records & 15u) || ((uintptr_t)d_offsets & 3u))
+        return fail(PSSBAM_EINVAL, "d_records must be 16-byte aligned, d_offsets 4-byte aligned");
+    HIP_TRY(hipSetDevice(e->device));
+    return launch_tally(e, (const uint8_t *)d_records, nbytes, d_offsets, n_records);
+}
+
+extern "C" int pssbam_engine_submit(pssbam_engine *e, const void *records, uint64_t nbytes, const uint32_t *offsets,
+                                    uint32_t n_records) {
+    int rc = check_ready(e);
+    if (rc) return rc;
+    if (!n_records) return PSSBAM_OK;
+    if (!records || !offsets) return fail(PSSBAM_EINVAL, "null buffer");
+    if (nbytes >= (1ull << 32)) return fail(PSSBAM_EINVAL, "record block must be < 4 GiB (got %llu)", (unsigned long long)nbytes);
+    if (offsets[n_records] != nbytes) return fail(PSSBAM_EFORMAT, "offsets[n_records] must equal nbytes");
+    HIP_TRY(hipSetDevice(e->device));
+    Slot &s = e->slots[e->next_slot];
+    e->next_slot ^= 1;
+    if (s.busy) HIP_TRY(hipEventSynchronize(s.consumed));  // the kernel that read this slot is done
+    s.busy = false;
+    if (s.recs_cap < nbytes + 64) {
+        if (s.d_recs) HIP_TRY(hipFree(s.d_recs));
+        s.d_recs = nullptr;
+        s.recs_cap = (size_t)(nbytes + nbytes / 4 + 4096);
+        HIP_TRY(hipMalloc(&s.d_recs, s.recs_cap));
+    }
+    if (s.offs_cap < (size_t)n_records + 1) {
+        if (s.d_offs) HIP_TRY(hipFree(s.d_offs));
+        s.d_offs = nullptr;
+        s.offs_cap = (size_t)n_records + n_records / 4 + 1024;
+        HIP_TRY(hipMalloc(&s.d_offs, s.offs_cap * sizeof(uint32_t)));
+    }
+    // H2D on the copy stream so it overlaps the previous block's kernel
+    HIP_TRY(hipMemcpyAsync(s.d_recs, records, nbytes, hipMemcpyHostToDevice, e->copy_stream));
+    HIP_TRY(hipMemcpyAsync(s.d_offs, offsets, ((size_t)n_records + 1) * sizeof(uint32_t), hipMemcpyHostToDevice,
+                           e->copy_stream));
+    HIP_TRY(hipEventRecord(s.copied, e->copy_stream));
+    HIP_TRY(hipStreamWaitEvent(e->stream, s.copied, 0));
+    rc = launch_tally(e, s.d_recs, nbytes, s.d_offs, n_records);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(s.consumed, e->stream));
+    s.busy = true;
+    // contract: the caller's buffers are free for reuse when we return
+    HIP_TRY(hipEventSynchronize(s.copied));
+    return PSSBAM_OK;
+}
+
+extern "C" int pssbam_engine_sync(pssbam_engine *e) {
+    if (!e) return fail(PSSBAM_EINVAL, "null engine");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->copy_stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return PSSBAM_OK;
+}
+
+extern "C" int pssbam_engine_finish(pssbam_engine *e, unsigned long *fwd, unsigned long *rev, uint64_t *k5,
+                                    uint64_t *k3, uint64_t stats[PSSBAM_ST_N]) {
+    int rc = pssbam_engine_sync(e);
+    if (rc) return rc;
+    std::vector<unsigned long long> h(e->n_counters);
+    HIP_TRY(hipMemcpy(h.data(), e->d_counters, e->n_counters * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    static_assert(sizeof(unsigned long) == 8, "LP64 expected");
+    const size_t tab = (size_t)e->rows * 16;
+    if (fwd) for (size_t i = 0; i < tab; i++) fwd[i] = (unsigned long)h[i];
+    if (rev) for (size_t i = 0; i < tab; i++) rev[i] = (unsigned long)h[e->off_rev + i];
+    if (k5) for (uint64_t i = 0; i < e->n_bins; i++) k5[i] = h[e->off_k5 + i];
+    if (k3) for (uint64_t i = 0; i < e->n_bins; i++) k3[i] = h[e->off_k3 + i];
+    if (stats) for (int i = 0; i < PSSBAM_ST_N; i++) stats[i] = h[e->off_stats + i];
+    return PSSBAM_OK;
+}
+
+extern "C" int pssbam_engine_reset(pssbam_engine *e) {
+    if (!e) return fail(PSSBAM_EINVAL, "null engine");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipMemsetAsync(e->d_counters, 0, e->n_counters * sizeof(unsigned long long), e->stream));
+    return PSSBAM_OK;
+}
+
+extern "C" int pssbam_engine_counters_device(pssbam_engine *e, void **d_counters, size_t *n_u64) {
+    if (!e || !d_counters || !n_u64) return fail(PSSBAM_EINVAL, "null argument");
+    *d_counters = e->d_counters;
+    *n_u64 = e->n_counters;
+    return PSSBAM_OK;
+}
+
+extern "C" int pssbam_engine_timer_begin(pssbam_engine *e) {
+    if (!e) return fail(PSSBAM_EINVAL, "null engine");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipEventRecord(e->t_begin, e->stream));
+    return PSSBAM_OK;
+}
+
+extern "C" int pssbam_engine_timer_end(pssbam_engine *e, float *ms) {
+    if (!e || !ms) return fail(PSSBAM_EINVAL, "null argument");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipEventRecord(e->t_end, e->stream));
+    HIP_TRY(hipEventSynchronize(e->t_end));
+    HIP_TRY(hipEventElapsedTime(ms, e->t_begin, e->t_end));
+    return PSSBAM_OK;
+}
+
+extern "C" int pssbam_engine_kernel_time(pssbam_engine *e, double *total_ms, uint64_t *n_launches, int reset) {
+    if (!e) return fail(PSSBAM_EINVAL, "null engine");
+    HIP_TRY(hipSetDevice(e->device));
+    int rc = resolve_launch_events(e);
+    if (rc) return rc;
+    if (total_ms) *total_ms = e->kernel_ms;
+    if (n_launches) *n_launches = e->kernel_launches;
+    if (reset) { e->kernel_ms = 0.0; e->kernel_launches = 0; }
+    return PSSBAM_OK;
+}
+
+// --------------------------------------------------------------------------------------
+// host helper: record index
+// --------------------------------------------------------------------------------------
+extern "C" int64_t pssbam_index_records(const void *bytes, uint64_t nbytes, uint32_t *offsets, uint64_t max_records,
+                                        uint64_t *consumed) {
+    const uint8_t *p = (const uint8_t *)bytes;
+    uint64_t o = 0, n = 0;
+    while (n < max_records && o + 4 <= nbytes && o < (1ull << 32) - 4) {
+        uint32_t bs;
+        memcpy(&bs, p + o, 4);
+        if (bs < 32) { fail(PSSBAM_EFORMAT, "record %llu: block_size %u < 32", (unsigned long long)n, bs); return PSSBAM_EFORMAT; }
+        const uint64_t next = o + 4 + (uint64_t)bs;
+        if (next > nbytes || next >= (1ull << 32)) break;  // partial record: caller supplies more bytes
+        if (offsets) offsets[n] = (uint32_t)o;
+        n++;
+        o = next;
+    }
+    if (offsets) offsets[n] = (uint32_t)o;
+    if (consumed) *consumed = o;
+    return (int64_t)n;
+}

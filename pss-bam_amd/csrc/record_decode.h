@@ -1,0 +1,327 @@
+// pss-bam_amd/csrc/record_decode.h -- device-side BAM record decode + the two tools'
+// filters, shared by every tally kernel.
+//
+// What is computed here is the *text-equivalent* reading of a binary BAM record: the
+// reference never sees BAM, it sees what `samtools view` prints and line2saml parses
+// (/root/reference/pss-bam.c:148-162, sam-parse.c:36-68).  The mapping (SURVEY 8a row
+// a2) is:
+//     RNAME  = name of refID ('*' when -1)        POS   = pos + 1
+//     CIGAR  = "<len><op>..." ('*' when n_cigar_op == 0)
+//     SEQ    = 4-bit codes through "=ACMGRSVTWYHKDBN" ('*' when l_seq == 0)
+//     QUAL   = phred+33, or '*' when the first byte is 0xFF (or l_seq == 0)
+//  => strlen(SEQ) = l_seq ? l_seq : 1; line2saml rejects the line (returns 1) when
+//     strlen(QUAL) differs, i.e. when QUAL is '*' but l_seq >= 2 (sam-parse.c:50).
+//
+// No CPU fallback exists for any of this: these functions are __device__ only.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pssbam {
+
+// ---- FLAG bits (sam-parse.c:53-64) --------------------------------------------------
+constexpr uint32_t FL_PAIRED = 0x1, FL_PROPER = 0x2, FL_UNMAP = 0x4, FL_MUNMAP = 0x8;
+constexpr uint32_t FL_REVERSE = 0x10, FL_READ1 = 0x40, FL_READ2 = 0x80;
+constexpr uint32_t FL_REJECT = 0x4 | 0x100 | 0x200 | 0x400 | 0x800;  // pss-bam.c:412-416, fragkon.c:142-146
+
+// ---- kernel parameter block (lives in kernarg/constant space) ------------------------
+struct TallyParams {
+    const uint8_t *recs;          // record block
+    const uint32_t *offs;         // n_recs + 1 offsets into recs
+    uint32_t n_recs;
+    uint32_t tally_mask;          // PSSBAM_TALLY_*
+    const uint8_t *genome;        // all contigs, 1 byte/base, zero padded between
+    const uint64_t *contig_start; // per genome contig (sorted-id order)
+    const uint64_t *contig_len;
+    const int32_t *ref_map;       // BAM refID -> genome contig, -1 = find_seq fails
+    int32_t n_ref;
+    int32_t star_contig;          // contig literally named "*" (refID -1), normally -1
+    // pss-bam options (pss-bam.c:12-18)
+    int32_t N;
+    uint32_t pss_min_mq;
+    uint64_t pss_min_len, pss_max_len;
+    uint32_t pss_merged_only;
+    uint32_t up_mask[8], down_mask[8];  // 256-bit membership sets for strchr(UP_CTX/DOWN_CTX, c)
+    // fragkon options (fragkon.c:14-18)
+    int32_t K;
+    uint32_t fk_min_mq;
+    uint64_t fk_min_len, fk_max_len;
+    uint32_t fk_merged_only;
+    // -R read group (NULL = keep all)
+    const uint8_t *rg;
+    uint32_t rg_len;
+    // output: one block of u64 counters [fwd | rev | k5 | k3 | stats]
+    unsigned long long *counters;
+    uint32_t off_rev, off_k5, off_k3, off_stats;
+    // tiled kernel geometry
+    uint32_t reads_per_tile;
+    uint32_t tile_bytes_cap;
+};
+
+// stats slots, must match include/pssbam_hip.h
+enum { ST_RECORDS = 0, ST_RG_DROPPED, ST_PARSE_SKIP, ST_NO_CONTIG, ST_PSS_OK, ST_PSS_FILTERED,
+       ST_KMER_OK, ST_KMER_FILTERED, ST_KMER_FAIL, ST_USED };
+
+// ---- byte sources -------------------------------------------------------------------
+// A record is read through one of these; both tolerate any alignment and never touch
+// bytes outside [0, limit) of the record they were built for.
+struct GlobalBytes {
+    const uint8_t *p;
+    __device__ __forceinline__ uint32_t u8(uint32_t o) const { return p[o]; }
+    __device__ __forceinline__ uint32_t u16(uint32_t o) const { return p[o] | (uint32_t(p[o + 1]) << 8); }
+    __device__ __forceinline__ uint32_t u32(uint32_t o) const {
+        return p[o] | (uint32_t(p[o + 1]) << 8) | (uint32_t(p[o + 2]) << 16) | (uint32_t(p[o + 3]) << 24);
+    }
+};
+
+// LDS window: dword-aligned reads + v_alignbyte; the window carries >= 8 bytes of slack
+// behind its last byte so the second dword of an unaligned read is always in bounds.
+struct LdsBytes {
+    const uint8_t *p;  // points into __shared__ storage
+    __device__ __forceinline__ uint32_t u8(uint32_t o) const { return p[o]; }
+    __device__ __forceinline__ uint32_t u32(uint32_t o) const {
+        const uint32_t a = (uint32_t)(uintptr_t)(p + o);
+        const uint32_t *q = (const uint32_t *)(p + o - (a & 3u));
+        return __builtin_amdgcn_alignbyte(q[1], q[0], a & 3u);
+    }
+    __device__ __forceinline__ uint32_t u16(uint32_t o) const { return u32(o) & 0xFFFFu; }
+};
+
+// ---- decoded fixed part of one record -------------------------------------------------
+struct RecHdr {
+    int32_t ref_id, pos, tlen;
+    uint32_t mapq, flag, n_cigar, l_seq, cigar0;
+    uint32_t seq_off, qual_off, aux_off;  // byte offsets from the record's block_size word
+    uint32_t rec_len;                     // 4 + block_size as given by the offset index
+    bool well_formed;                     // variable-length parts fit in rec_len
+};
+
+template <class Src>
+__device__ __forceinline__ RecHdr decode_hdr(const Src &src, uint32_t rec_len) {
+    RecHdr h;
+    h.rec_len = rec_len;
+    h.well_formed = rec_len >= 36;
+    if (!h.well_formed) {
+        h.ref_id = -1; h.pos = -1; h.tlen = 0; h.mapq = 0; h.flag = FL_UNMAP; h.n_cigar = 0; h.l_seq = 0;
+        h.cigar0 = 0; h.seq_off = h.qual_off = h.aux_off = rec_len;
+        return h;
+    }
+    // SAM spec 4.2: block_size, refID, pos, l_read_name:8 mapq:8 bin:16, n_cigar_op:16 flag:16,
+    //               l_seq, next_refID, next_pos, tlen
+    h.ref_id = (int32_t)src.u32(4);
+    h.pos = (int32_t)src.u32(8);
+    const uint32_t w3 = src.u32(12);
+    const uint32_t w4 = src.u32(16);
+    h.l_seq = src.u32(20);
+    h.tlen = (int32_t)src.u32(32);
+    const uint32_t l_read_name = w3 & 0xFFu;
+    h.mapq = (w3 >> 8) & 0xFFu;
+    h.n_cigar = w4 & 0xFFFFu;
+    h.flag = w4 >> 16;
+    const uint64_t cig_off = 36ull + l_read_name;
+    const uint64_t seq_off = cig_off + 4ull * h.n_cigar;
+    const uint64_t qual_off = seq_off + ((uint64_t(h.l_seq) + 1) >> 1);
+    const uint64_t aux_off = qual_off + h.l_seq;
+    h.well_formed = aux_off <= rec_len;
+    if (!h.well_formed) {
+        h.n_cigar = 0; h.l_seq = 0; h.cigar0 = 0; h.flag |= FL_UNMAP;
+        h.seq_off = h.qual_off = h.aux_off = rec_len;
+        return h;
+    }
+    h.seq_off = (uint32_t)seq_off;
+    h.qual_off = (uint32_t)qual_off;
+    h.aux_off = (uint32_t)aux_off;
+    h.cigar0 = h.n_cigar ? src.u32((uint32_t)cig_off) : 0u;
+    return h;
+}
+
+// `samtools view -r RG`: keep the record iff it carries RG:Z:<rg>.  Walks the aux
+// fields (SAM spec 4.2.4); a field that runs past the record ends the walk.
+template <class Src>
+__device__ bool has_read_group(const Src &src, const RecHdr &h, const uint8_t *rg, uint32_t rg_len) {
+    uint32_t o = h.aux_off;
+    const uint32_t end = h.rec_len;
+    while (o + 3 <= end) {
+        const uint32_t t0 = src.u8(o), t1 = src.u8(o + 1), ty = src.u8(o + 2);
+        o += 3;
+        uint32_t sz;
+        switch (ty) {
+        case 'A': case 'c': case 'C': sz = 1; break;
+        case 's': case 'S': sz = 2; break;
+        case 'i': case 'I': case 'f': sz = 4; break;
+        case 'Z': case 'H': {
+            const bool is_rg = (t0 == 'R' && t1 == 'G' && ty == 'Z');
+            uint32_t n = 0;
+            bool same = is_rg;
+            while (o + n < end) {
+                const uint32_t c = src.u8(o + n);
+                if (c == 0) break;
+                if (same) same = (n < rg_len) && (rg[n] == c);
+                n++;
+            }
+            if (o + n >= end) return false;            // unterminated string
+            if (is_rg) return same && n == rg_len;      // first RG tag decides, like bam_aux_get
+            sz = n + 1;
+            break;
+        }
+        case 'B': {
+            if (o + 5 > end) return false;
+            const uint32_t sub = src.u8(o);
+            const uint32_t cnt = src.u32(o + 1);
+            const uint32_t es = (sub == 'c' || sub == 'C') ? 1u : (sub == 's' || sub == 'S') ? 2u : 4u;
+            const uint64_t tot = 5ull + uint64_t(cnt) * es;
+            if (tot > end - o) return false;
+            sz = (uint32_t)tot;
+            break;
+        }
+        default: return false;
+        }
+        if (sz > end - o) return false;
+        o += sz;
+    }
+    return false;
+}
+
+// ---- base codes ----------------------------------------------------------------------
+// genome byte -> A0 C1 G2 T3, 4 = anything else (pss-bam.c:205-251, kmer.c:190-208).
+__device__ __forceinline__ uint32_t ref_code(uint32_t b) {
+    return b == 'A' ? 0u : b == 'C' ? 1u : b == 'G' ? 2u : b == 'T' ? 3u : 4u;
+}
+// BAM 4-bit code -> same scale: 1(A) 2(C) 4(G) 8(T); every other code prints as a
+// non-ACGT letter ("=MRSVWYHKDBN") and never matches a pair string.
+__device__ __forceinline__ uint32_t nib_code(uint32_t n) {
+    return n == 1 ? 0u : n == 2 ? 1u : n == 4 ? 2u : n == 8 ? 3u : 4u;
+}
+// one byte of do_revcomp on an upper-case genome byte (pss-bam.c:60-79)
+__device__ __forceinline__ uint32_t comp_byte(uint32_t b) {
+    return b == 'A' ? 'T' : b == 'C' ? 'G' : b == 'G' ? 'C' : b == 'T' ? 'A'
+         : b == 'a' ? 'T' : b == 'c' ? 'G' : b == 'g' ? 'C' : b == 't' ? 'A' : b;
+}
+__device__ __forceinline__ bool in_set(const uint32_t (&m)[8], uint32_t b) { return (m[(b >> 5) & 7] >> (b & 31)) & 1u; }
+
+template <class Src>
+__device__ __forceinline__ uint32_t read_nibble(const Src &src, const RecHdr &h, uint32_t i) {
+    // base i of SEQ; i >= l_seq (only reachable for out-of-contract records, P3) reads as 0
+    if (i >= h.l_seq) return 0u;
+    const uint32_t b = src.u8(h.seq_off + (i >> 1));
+    return (i & 1u) ? (b & 0xFu) : (b >> 4);
+}
+
+// ---- what to do with one record ---------------------------------------------------------
+struct Plan {
+    uint32_t st_mask;        // bit per stats slot this record increments
+    bool live;               // record reached process_aln with a known contig
+    uint64_t gbase;          // genome offset of the contig's first base
+    int64_t s;               // 0-based alignment start
+    bool rev;                // FLAG 0x10
+    // pss
+    bool pss_fwd, pss_rev;   // which table(s) this read is tallied into
+    uint32_t L;              // pss effective length: |TLEN| when paired else strlen(SEQ)
+    // fragkon
+    bool fk5, fk3;           // which k-mer table(s) this read may add to
+    uint32_t Lk;             // strlen(SEQ)
+};
+
+// Text-equivalence + contig lookup + both tools' filters.  Genome bytes are read for the
+// -U/-D context test only.
+template <class Src>
+__device__ Plan make_plan(const TallyParams &P, const Src &src, const RecHdr &h) {
+    Plan pl;
+    pl.st_mask = 1u << ST_RECORDS;
+    pl.live = false;
+    pl.pss_fwd = pl.pss_rev = pl.fk5 = pl.fk3 = false;
+    pl.gbase = 0; pl.s = 0; pl.rev = false; pl.L = 0; pl.Lk = 0;
+
+    if (P.rg && !has_read_group(src, h, P.rg, P.rg_len)) { pl.st_mask |= 1u << ST_RG_DROPPED; return pl; }
+
+    // line2saml: strlen(SEQ) vs strlen(QUAL)  (sam-parse.c:50)
+    const uint32_t l_text = h.l_seq ? h.l_seq : 1u;
+    const bool qual_star = (h.l_seq == 0) || (src.u8(h.qual_off) == 0xFFu);
+    if (!h.well_formed || (qual_star && l_text != 1u)) { pl.st_mask |= 1u << ST_PARSE_SKIP; return pl; }
+
+    // find_seq(genome, RNAME)  (pss-bam.c:393-396, fragkon.c:124-127)
+    int32_t contig = -1;
+    if (h.ref_id >= 0 && h.ref_id < P.n_ref) contig = P.ref_map[h.ref_id];
+    else if (h.ref_id == -1) contig = P.star_contig;
+    if (contig < 0) { pl.st_mask |= 1u << ST_NO_CONTIG; return pl; }
+    const uint64_t glen = P.contig_len[contig];
+    pl.gbase = P.contig_start[contig];
+    pl.live = true;
+    pl.s = h.pos;  // POS-1
+    pl.rev = (h.flag & FL_REVERSE) != 0;
+    const bool paired = (h.flag & FL_PAIRED) != 0;
+    const uint32_t op_len = h.cigar0 >> 4;
+    const bool single_m = (h.n_cigar == 1) && ((h.cigar0 & 0xFu) == 0u);  // cigar_ok: "<len>M"
+    const uint8_t *G = P.genome + pl.gbase;
+
+    if (P.tally_mask & 1u) {
+        // process_aln filters, pss-bam.c:401-420
+        const uint32_t L = paired ? (uint32_t)(h.tlen < 0 ? -(int64_t)h.tlen : (int64_t)h.tlen) : l_text;
+        pl.L = L;
+        bool ok = glen > 0 && pl.s >= 2 && (uint64_t)(pl.s + (int64_t)L + 2) <= glen;
+        ok = ok && !(h.mapq < P.pss_min_mq);
+        ok = ok && (uint64_t)L >= P.pss_min_len && (uint64_t)L <= P.pss_max_len && (int64_t)L >= (int64_t)P.N;
+        ok = ok && single_m && op_len == L;
+        ok = ok && !(h.flag & FL_REJECT) && !(P.pss_merged_only && paired);
+        if (ok) {
+            // first context base each side, in read orientation (pss-bam.c:134-142, :461, :472)
+            const uint32_t up = pl.rev ? comp_byte(G[pl.s + L]) : G[pl.s - 1];
+            const uint32_t dn = pl.rev ? comp_byte(G[pl.s - 1]) : G[pl.s + L];
+            const bool up_ok = in_set(P.up_mask, up), dn_ok = in_set(P.down_mask, dn);
+            if (!paired) {
+                pl.pss_fwd = pl.pss_rev = up_ok && dn_ok;                       // :428-447
+            } else if ((h.flag & FL_PROPER) && !(h.flag & FL_MUNMAP)) {         // :450-494
+                if ((h.flag & FL_READ1) && up_ok) pl.pss_fwd = true;
+                else if ((h.flag & FL_READ2) && dn_ok) pl.pss_rev = true;
+            }
+        }
+        pl.st_mask |= (pl.pss_fwd || pl.pss_rev) ? (1u << ST_PSS_OK) : (1u << ST_PSS_FILTERED);
+    }
+    if (P.tally_mask & 2u) {
+        // process_aln filters, fragkon.c:129-146 (+ precondition P4: start >= k/2)
+        const uint32_t L = l_text;
+        const uint32_t okk = (uint32_t)P.K / 2u;
+        pl.Lk = L;
+        bool ok = glen > 0 && pl.s >= (int64_t)okk && (uint64_t)(pl.s + (int64_t)L + okk) <= glen;
+        ok = ok && h.mapq >= P.fk_min_mq;
+        ok = ok && (uint64_t)L >= P.fk_min_len && (uint64_t)L <= P.fk_max_len;
+        ok = ok && single_m && op_len == L;
+        ok = ok && !(h.flag & FL_REJECT);
+        if (ok) {
+            if (!paired) {
+                pl.fk5 = pl.fk3 = true;                                          // :149-183
+            } else if (!P.fk_merged_only && (h.flag & FL_PROPER) && !(h.flag & FL_MUNMAP)) {  // :187-213
+                if (h.flag & FL_READ1) pl.fk5 = true;
+                else if (h.flag & FL_READ2) pl.fk3 = true;
+            }
+        }
+        if (!pl.fk5 && !pl.fk3) pl.st_mask |= 1u << ST_KMER_FILTERED;
+    }
+    return pl;
+}
+
+// Bin of the k bases G[w0 .. w0+k) (forward strand) or of their reverse complement.
+// Returns false when any base is not ACGT (add_to_ksp returns -1, kmer.c:55-111).
+// Windows (closed form of fragkon.c:152-181):
+//   fwd 5' = G[s-ok, k)        fwd 3' = G[s+L-ik, k)
+//   rev 5' = rc(G[s+L-ok, k))  rev 3' = rc(G[s-ok+(ik-ok), k))
+__device__ __forceinline__ bool kmer_bin(const uint8_t *G, int64_t w0, int K, bool rc, uint32_t &bin) {
+    uint32_t b = 0;
+    bool ok = true;
+    for (int t = 0; t < K; t++) {
+        const uint32_t c = ref_code(rc ? G[w0 + (K - 1 - t)] : G[w0 + t]);
+        ok = ok && (c < 4u);
+        b = (b << 2) | ((rc ? 3u - c : c) & 3u);
+    }
+    bin = b;
+    return ok;
+}
+
+__device__ __forceinline__ void kmer_windows(const Plan &pl, int K, int64_t &w5, int64_t &w3) {
+    const int64_t ok = K / 2, ik = K - K / 2;
+    if (!pl.rev) { w5 = pl.s - ok; w3 = pl.s + (int64_t)pl.Lk - ik; }
+    else { w5 = pl.s + (int64_t)pl.Lk - ok; w3 = pl.s - ok + (ik - ok); }
+}
+
+}  // namespace pssbam

@@ -593,3 +593,54 @@ def random_fk_opts(rng: np.random.Generator) -> FkOpts:
     hi = int(rng.choice([250000000, 250000000, 60, 120]))
     return FkOpts(klen=int(rng.choice([1, 2, 3, 4, 5, 6, 8, 9])), min_mq=int(rng.choice([0, 0, 20, 37])),
                   min_read_len=lo, max_read_len=hi, merged_only=bool(rng.random() < 0.3))
+
+
+# ----------------------------------------------------------------------------------
+# a minimal, independent BAM reader (tests only; the product reader is C)
+# ----------------------------------------------------------------------------------
+
+
+def bgzf_inflate(data: bytes) -> bytes:
+    out, i = [], 0
+    while i < len(data):
+        assert data[i:i + 4] == b"\x1f\x8b\x08\x04", "not a BGZF block"
+        xlen = struct.unpack_from("<H", data, i + 10)[0]
+        bsize = None
+        j = i + 12
+        while j < i + 12 + xlen:
+            si1, si2, slen = data[j], data[j + 1], struct.unpack_from("<H", data, j + 2)[0]
+            if si1 == 66 and si2 == 67:
+                bsize = struct.unpack_from("<H", data, j + 4)[0]
+            j += 4 + slen
+        assert bsize is not None
+        cdata = data[i + 12 + xlen:i + bsize + 1 - 8]
+        out.append(zlib.decompress(cdata, -15))
+        i += bsize + 1
+    return b"".join(out)
+
+
+def read_bam(path: Path) -> tuple[list[tuple[str, int]], np.ndarray]:
+    """-> (refs[(name, len)], raw alignment-record bytes as uint8 array)"""
+    raw = bgzf_inflate(Path(path).read_bytes())
+    assert raw[:4] == b"BAM\1"
+    l_text = struct.unpack_from("<i", raw, 4)[0]
+    o = 8 + l_text
+    n_ref = struct.unpack_from("<i", raw, o)[0]
+    o += 4
+    refs = []
+    for _ in range(n_ref):
+        ln = struct.unpack_from("<i", raw, o)[0]
+        name = raw[o + 4:o + 4 + ln - 1].decode()
+        refs.append((name, struct.unpack_from("<i", raw, o + 4 + ln)[0]))
+        o += 8 + ln
+    return refs, np.frombuffer(raw, dtype=np.uint8, offset=o).copy()
+
+
+def raw_records(refs: list[tuple[str, int]], recs: list[Rec]) -> np.ndarray:
+    idx = {n: i for i, (n, _) in enumerate(refs)}
+    return np.frombuffer(b"".join(bam_record(r, idx) for r in recs), dtype=np.uint8).copy()
+
+
+def loaded_contigs(contigs: list[tuple[str, str]]) -> list[tuple[str, np.ndarray]]:
+    """FASTA text form -> the in-memory form init_genome produces (upper case bytes)"""
+    return [(cid, np.frombuffer(seq.upper().encode(), dtype=np.uint8).copy()) for cid, seq in contigs]

@@ -1,0 +1,60 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds for gfx950, loads,
+exports every symbol include/pssbam_hip.h declares, and refuses to run without a GPU
+(no CPU fallback exists).  No compute is attempted here."""
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import __graft_entry__ as ge
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    ge.build()
+    return ge.load_pkg()
+
+
+def test_header_symbols_are_exported(pkg):
+    hdr = (ROOT / "include" / "pssbam_hip.h").read_text()
+    declared = set(re.findall(r"\b(pssbam_[a-z_]+)\s*\(", hdr))
+    declared -= {"pssbam_engine"}
+    assert declared == set(pkg.HIP_SYMBOLS), declared ^ set(pkg.HIP_SYMBOLS)
+    lib = pkg.hip_lib()
+    for s in declared:
+        assert hasattr(lib, s), s
+
+
+def test_code_object_is_gfx950_only(pkg):
+    """the fat binary inside the shared library carries gfx950 code and nothing else"""
+    blob = pkg.LIB_HIP.read_bytes()
+    targets = set(re.findall(rb"amdgcn-amd-amdhsa--(gfx[0-9a-z]+)", blob))
+    assert targets == {b"gfx950"}, targets
+
+
+def test_index_records_host_helper(pkg):
+    import pssbam_testlib as tl
+    contigs, refs, recs = tl.fuzz_dataset(3, 200)
+    raw = tl.raw_records(refs, recs)
+    offs = pkg.index_records(raw)
+    assert offs.size == len(recs) + 1 and offs[0] == 0 and int(offs[-1]) == raw.size
+    # a trailing partial record is left for the caller
+    offs2 = pkg.index_records(raw[:-5])
+    assert offs2.size == len(recs) and int(offs2[-1]) == int(offs[-2])
+    # block_size < 32 is malformed
+    bad = raw.copy()
+    bad[0:4] = np.frombuffer((7).to_bytes(4, "little"), dtype=np.uint8)
+    with pytest.raises(pkg.PssbamError):
+        pkg.index_records(bad)
+
+
+def test_engine_refuses_without_gpu(pkg):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(pkg.PssbamError) as ei:
+        pkg.Engine(pss=dict(region_len=15))
+    assert "no HIP device" in str(ei.value) or "-2" in str(ei.value)

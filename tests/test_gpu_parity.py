@@ -1,0 +1,214 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI (ctypes), against the
+oracle on the same seeded inputs and against the committed golden vectors.  Bit-exact
+(integer work)."""
+import json
+import os
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import __graft_entry__ as ge
+import pssbam_testlib as tl
+
+pytestmark = pytest.mark.gpu
+
+GOLD = Path(__file__).resolve().parent / "golden"
+MANIFEST = json.loads((GOLD / "manifest.json").read_text())
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    p = ge.load_pkg()
+    assert p.LIB_HIP.exists(), "libpssbam_hip.so missing: the HIP path must be built, there is no fallback"
+    return p
+
+
+def _engine_tables(pkg, contigs, refs, raw, pss=None, kmer=None, rg=None, kernel=0, chunks=1):
+    eng = pkg.Engine(pss=pss, kmer=kmer, read_group=rg, kernel=kernel)
+    try:
+        eng.set_genome_arrays(tl.loaded_contigs(contigs))
+        eng.set_references([n for n, _ in refs])
+        offs = pkg.index_records(raw)
+        n = offs.size - 1
+        cuts = [n * i // chunks for i in range(chunks + 1)]
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            if b > a:
+                o = offs[a:b + 1].astype(np.int64)
+                eng.submit(raw[o[0]:o[-1]], (o - o[0]).astype(np.uint32))
+        return eng.finish()
+    finally:
+        eng.close()
+
+
+def _pss_dict(o: tl.PssOpts):
+    return dict(region_len=o.region_len, min_read_len=o.min_read_len, max_read_len=o.max_read_len, min_mq=o.min_mq,
+                up_ctx=o.up_ctx, down_ctx=o.down_ctx, merged_only=o.merged_only)
+
+
+def _fk_dict(o: tl.FkOpts):
+    return dict(klen=o.klen, min_mq=o.min_mq, min_read_len=o.min_read_len, max_read_len=o.max_read_len,
+                merged_only=o.merged_only)
+
+
+def _check_pss(got, want_fwd, want_rev, st):
+    assert np.array_equal(got.fwd, want_fwd), "forward table differs"
+    assert np.array_equal(got.rev, want_rev), "reverse table differs"
+    assert got.stats["parse_skip"] == st[tl.ST_PARSE_SKIP]
+    assert got.stats["no_contig"] == st[tl.ST_NO_CONTIG]
+    assert got.stats["pss_ok"] == st[tl.ST_OK]
+    assert got.stats["pss_filtered"] == st[tl.ST_FILTERED]
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_fuzz_both_kernels_match_oracle(pkg, oracle, tmp_path, seed):
+    """random records x random options, text for the oracle / binary for the engine, the
+    two encodings written independently from the same record list"""
+    contigs, refs, recs = tl.fuzz_dataset(300 + seed, 2500)
+    fa, sam = tmp_path / "g.fa", tmp_path / "a.sam"
+    tl.write_fasta(fa, contigs)
+    tl.write_sam(sam, refs, recs)
+    raw = tl.raw_records(refs, recs)
+    g = oracle.load_genome(fa)
+    rng = np.random.default_rng(seed)
+    try:
+        for trial in range(4):
+            po = tl.PssOpts() if trial == 0 else tl.random_pss_opts(rng)
+            ko = tl.FkOpts(klen=4) if trial == 0 else tl.random_fk_opts(rng)
+            wf, wr, st = oracle.pss(g, sam, po)
+            w5, w3, stk = oracle.fragkon(g, sam, ko)
+            kernels = [pkg.KERNEL_SIMPLE] + ([pkg.KERNEL_TILED] if po.region_len <= 30 else [])
+            for kern in kernels:
+                got = _engine_tables(pkg, contigs, refs, raw, pss=_pss_dict(po), kmer=_fk_dict(ko), kernel=kern,
+                                     chunks=1 + trial)
+                _check_pss(got, wf, wr, st)
+                assert np.array_equal(got.k5, w5.astype(np.uint64)), f"5' k-mers differ ({ko})"
+                assert np.array_equal(got.k3, w3.astype(np.uint64)), f"3' k-mers differ ({ko})"
+                assert got.stats["kmer_ok"] == stk[tl.ST_OK]
+                assert got.stats["kmer_filtered"] == stk[tl.ST_FILTERED]
+                assert got.stats["kmer_fail"] == stk[tl.ST_KMER_FAIL]
+                assert got.stats["records"] == len(recs)
+    finally:
+        oracle.free_genome(g)
+
+
+@pytest.mark.parametrize("case", [c for c in MANIFEST["cases"] if c["tool"] == "pss-bam"],
+                         ids=lambda c: c["prefix"])
+def test_golden_pss_from_bam(pkg, case):
+    """the committed BAM fixture through the engine == the reference's committed output"""
+    ds = MANIFEST["datasets"][case["dataset"]]
+    o = tl.PssOpts(**case["opts"])
+    refs, raw = tl.read_bam(GOLD / ds["bam"])
+    fa_txt = (GOLD / ds["fasta"]).read_text()
+    contigs = [(blk.split("\n", 1)[0].split()[0], "".join(blk.split("\n")[1:])) for blk in fa_txt.split(">")[1:]]
+    wf, wr = tl.parse_counts_text((GOLD / case["counts"]).read_text())
+    for kern in (pkg.KERNEL_SIMPLE, pkg.KERNEL_TILED) if o.region_len <= 30 else (pkg.KERNEL_SIMPLE,):
+        got = _engine_tables(pkg, contigs, refs, raw, pss=_pss_dict(o), rg=o.read_group, kernel=kern)
+        assert np.array_equal(got.fwd, wf) and np.array_equal(got.rev, wr)
+
+
+@pytest.mark.parametrize("case", [c for c in MANIFEST["cases"] if c["tool"] == "fragkon"],
+                         ids=lambda c: c["stdout"])
+def test_golden_fragkon_from_bam(pkg, case):
+    ds = MANIFEST["datasets"][case["dataset"]]
+    o = tl.FkOpts(**case["opts"])
+    refs, raw = tl.read_bam(GOLD / ds["bam"])
+    fa_txt = (GOLD / ds["fasta"]).read_text()
+    contigs = [(blk.split("\n", 1)[0].split()[0], "".join(blk.split("\n")[1:])) for blk in fa_txt.split(">")[1:]]
+    w5, w3 = tl.parse_fragkon_text((GOLD / case["stdout"]).read_text())
+    for kern in (pkg.KERNEL_SIMPLE, pkg.KERNEL_TILED):
+        got = _engine_tables(pkg, contigs, refs, raw, kmer=_fk_dict(o), kernel=kern)
+        assert np.array_equal(np.minimum(got.k5, 0xFFFFFFFF).astype(np.uint32), w5)
+        assert np.array_equal(np.minimum(got.k3, 0xFFFFFFFF).astype(np.uint32), w3)
+
+
+def test_read_group_filter(pkg, oracle, tmp_path):
+    contigs, refs, recs = tl.fuzz_dataset(901, 2000, with_rg=True)
+    fa = tmp_path / "g.fa"
+    tl.write_fasta(fa, contigs)
+    raw = tl.raw_records(refs, recs)
+    g = oracle.load_genome(fa)
+    try:
+        for rg in ("grpA", "grpB", "grp", "nope"):
+            keep = [r for r in recs if ("RG", "Z", rg) in r.tags]
+            sam = tmp_path / f"{rg}.sam"
+            tl.write_sam(sam, refs, keep)
+            po = tl.PssOpts(region_len=12)
+            wf, wr, st = oracle.pss(g, sam, po)
+            for kern in (pkg.KERNEL_SIMPLE, pkg.KERNEL_TILED):
+                got = _engine_tables(pkg, contigs, refs, raw, pss=_pss_dict(po), rg=rg, kernel=kern)
+                _check_pss(got, wf, wr, st)
+                assert got.stats["rg_dropped"] == len(recs) - len(keep)
+    finally:
+        oracle.free_genome(g)
+
+
+def test_edges_empty_ragged_accumulate_reset(pkg, oracle, tmp_path):
+    contigs, refs, recs = tl.fuzz_dataset(55, 700)
+    fa, sam = tmp_path / "g.fa", tmp_path / "a.sam"
+    tl.write_fasta(fa, contigs)
+    tl.write_sam(sam, refs, recs)
+    g = oracle.load_genome(fa)
+    wf, wr, _ = oracle.pss(g, sam, tl.PssOpts(region_len=10))
+    oracle.free_genome(g)
+    raw = tl.raw_records(refs, recs)
+    offs = pkg.index_records(raw)
+    eng = pkg.Engine(pss=dict(region_len=10))
+    eng.set_genome_arrays(tl.loaded_contigs(contigs))
+    eng.set_references([n for n, _ in refs])
+    eng.submit(np.zeros(0, dtype=np.uint8), np.zeros(1, dtype=np.uint32))      # empty block
+    z = eng.finish()
+    assert z.fwd.sum() == 0 and z.stats["records"] == 0
+    # ragged: blocks of 1, 2, 3, ... records
+    a, step = 0, 1
+    n = offs.size - 1
+    while a < n:
+        b = min(n, a + step)
+        o = offs[a:b + 1].astype(np.int64)
+        eng.submit(raw[o[0]:o[-1]], (o - o[0]).astype(np.uint32))
+        a, step = b, step + 1
+    once = eng.finish()
+    assert np.array_equal(once.fwd, wf) and np.array_equal(once.rev, wr)
+    eng.submit(raw, offs)                                                        # accumulates
+    twice = eng.finish()
+    assert np.array_equal(twice.fwd, 2 * wf) and np.array_equal(twice.rev, 2 * wr)
+    eng.reset()
+    assert eng.finish().fwd.sum() == 0
+    eng.close()
+
+
+def test_tile_overflow_path(pkg, oracle, tmp_path, monkeypatch):
+    """records larger than the LDS staging window take the global-memory path of the
+    tiled kernel; force it with a tiny window"""
+    contigs, refs, recs = tl.fuzz_dataset(77, 1500)
+    fa, sam = tmp_path / "g.fa", tmp_path / "a.sam"
+    tl.write_fasta(fa, contigs)
+    tl.write_sam(sam, refs, recs)
+    g = oracle.load_genome(fa)
+    po, ko = tl.PssOpts(region_len=7), tl.FkOpts(klen=3)
+    wf, wr, st = oracle.pss(g, sam, po)
+    w5, w3, _ = oracle.fragkon(g, sam, ko)
+    oracle.free_genome(g)
+    raw = tl.raw_records(refs, recs)
+    monkeypatch.setenv("PSSBAM_TILE_READS", "64")
+    monkeypatch.setenv("PSSBAM_TILE_CAP", "2048")
+    got = _engine_tables(pkg, contigs, refs, raw, pss=_pss_dict(po), kmer=_fk_dict(ko), kernel=pkg.KERNEL_TILED)
+    _check_pss(got, wf, wr, st)
+    assert np.array_equal(got.k5, w5.astype(np.uint64)) and np.array_equal(got.k3, w3.astype(np.uint64))
+
+
+def test_large_region_len_uses_generic_kernel(pkg, oracle, tmp_path):
+    contigs, refs, recs = tl.fuzz_dataset(88, 1500)
+    fa, sam = tmp_path / "g.fa", tmp_path / "a.sam"
+    tl.write_fasta(fa, contigs)
+    tl.write_sam(sam, refs, recs)
+    g = oracle.load_genome(fa)
+    raw = tl.raw_records(refs, recs)
+    try:
+        for n in (31, 64, 200, 1100):
+            po = tl.PssOpts(region_len=n)
+            wf, wr, st = oracle.pss(g, sam, po)
+            got = _engine_tables(pkg, contigs, refs, raw, pss=_pss_dict(po))     # AUTO
+            _check_pss(got, wf, wr, st)
+    finally:
+        oracle.free_genome(g)
