@@ -152,6 +152,12 @@ int pssbam_engine_reset(pssbam_engine *e);
  * n_u64 64-bit words, for a caller-side RCCL reduce across GPUs (sum, uint64). */
 int pssbam_engine_counters_device(pssbam_engine *e, void **d_counters, size_t *n_u64);
 
+/* Makes the engine accumulate into caller-owned device memory (n_u64 words, as reported
+ * by pssbam_engine_counters_device, 8-byte aligned, zeroed by the caller) -- e.g. a
+ * torch tensor that is then handed to torch.distributed / RCCL in place.  The current
+ * counts are carried over.  NULL returns to the engine's own block. */
+int pssbam_engine_bind_counters(pssbam_engine *e, void *d_counters, size_t n_u64);
+
 /* HIP-event stopwatch on the engine's stream: begin records an event, end records a
  * second one, waits for it and returns the elapsed device time in milliseconds. */
 int pssbam_engine_timer_begin(pssbam_engine *e);

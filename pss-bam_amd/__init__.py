@@ -33,7 +33,8 @@ HIP_SYMBOLS = [
     "pssbam_last_error", "pssbam_device_count", "pssbam_engine_create", "pssbam_engine_destroy",
     "pssbam_engine_set_stream", "pssbam_engine_set_genome", "pssbam_engine_set_genome_arrays",
     "pssbam_engine_set_references", "pssbam_engine_submit", "pssbam_engine_submit_device", "pssbam_engine_sync",
-    "pssbam_engine_finish", "pssbam_engine_reset", "pssbam_engine_counters_device", "pssbam_engine_timer_begin",
+    "pssbam_engine_finish", "pssbam_engine_reset", "pssbam_engine_counters_device", "pssbam_engine_bind_counters",
+    "pssbam_engine_timer_begin",
     "pssbam_engine_timer_end", "pssbam_engine_kernel_time", "pssbam_index_records",
 ]
 
@@ -90,6 +91,7 @@ def hip_lib() -> C.CDLL:
     L.pssbam_engine_finish.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.pssbam_engine_reset.argtypes = [C.c_void_p]
     L.pssbam_engine_counters_device.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    L.pssbam_engine_bind_counters.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     L.pssbam_engine_timer_begin.argtypes = [C.c_void_p]
     L.pssbam_engine_timer_end.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     L.pssbam_engine_kernel_time.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]
@@ -234,6 +236,16 @@ class Engine:
         ptr, n = C.c_void_p(), C.c_size_t()
         _chk(self._L.pssbam_engine_counters_device(self._h, C.byref(ptr), C.byref(n)))
         return int(ptr.value), int(n.value)
+
+    def bind_counters(self, d_ptr: int | None, n_u64: int = 0):
+        _chk(self._L.pssbam_engine_bind_counters(self._h, C.c_void_p(d_ptr) if d_ptr else None, n_u64))
+
+    def counter_layout(self) -> dict:
+        """u64-word offsets of the sections of the counter block"""
+        rows = (self.region_len + 2) if self.has_pss else 0
+        nb = 4 ** self.klen if self.has_kmer else 0
+        return {"fwd": 0, "rev": rows * 16, "k5": 2 * rows * 16, "k3": 2 * rows * 16 + nb,
+                "stats": 2 * rows * 16 + 2 * nb, "rows": rows, "bins": nb}
 
     def timer_begin(self):
         _chk(self._L.pssbam_engine_timer_begin(self._h))

@@ -90,7 +90,8 @@ struct pssbam_engine {
     // -R
     uint8_t *d_rg = nullptr;
     // counters
-    unsigned long long *d_counters = nullptr;
+    unsigned long long *d_counters = nullptr;      // block in use (own or caller-bound)
+    unsigned long long *d_counters_own = nullptr;  // the engine's own allocation
     size_t n_counters = 0;
     uint32_t rows = 0, off_rev = 0, off_k5 = 0, off_k3 = 0, off_stats = 0;
     uint64_t n_bins = 0;
@@ -175,7 +176,8 @@ extern "C" int pssbam_engine_create(const pssbam_config *cfg, pssbam_engine **ou
     e->off_k3 = (uint32_t)(e->off_k5 + e->n_bins);
     e->off_stats = (uint32_t)(e->off_k3 + e->n_bins);
     e->n_counters = (size_t)e->off_stats + PSSBAM_ST_N;
-    HIP_TRY(hipMalloc(&e->d_counters, e->n_counters * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc(&e->d_counters_own, e->n_counters * sizeof(unsigned long long)));
+    e->d_counters = e->d_counters_own;
     HIP_TRY(hipMemsetAsync(e->d_counters, 0, e->n_counters * sizeof(unsigned long long), e->stream));
     if (e->has_rg) {
         HIP_TRY(hipMalloc(&e->d_rg, e->rg.size() + 16));
@@ -213,7 +215,7 @@ extern "C" void pssbam_engine_destroy(pssbam_engine *e) {
     if (e->d_contig_len) (void)hipFree(e->d_contig_len);
     if (e->d_ref_map) (void)hipFree(e->d_ref_map);
     if (e->d_rg) (void)hipFree(e->d_rg);
-    if (e->d_counters) (void)hipFree(e->d_counters);
+    if (e->d_counters_own) (void)hipFree(e->d_counters_own);
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
     if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
     delete e;
@@ -542,6 +544,20 @@ extern "C" int pssbam_engine_counters_device(pssbam_engine *e, void **d_counters
     if (!e || !d_counters || !n_u64) return fail(PSSBAM_EINVAL, "null argument");
     *d_counters = e->d_counters;
     *n_u64 = e->n_counters;
+    return PSSBAM_OK;
+}
+
+extern "C" int pssbam_engine_bind_counters(pssbam_engine *e, void *d_counters, size_t n_u64) {
+    if (!e) return fail(PSSBAM_EINVAL, "null engine");
+    HIP_TRY(hipSetDevice(e->device));
+    unsigned long long *target = d_counters ? (unsigned long long *)d_counters : e->d_counters_own;
+    if (d_counters && (n_u64 != e->n_counters || ((uintptr_t)d_counters & 7u)))
+        return fail(PSSBAM_EINVAL, "bound counter block must hold exactly %zu aligned u64 words", e->n_counters);
+    if (target != e->d_counters) {
+        HIP_TRY(hipMemcpyAsync(target, e->d_counters, e->n_counters * sizeof(unsigned long long),
+                               hipMemcpyDeviceToDevice, e->stream));
+        e->d_counters = target;
+    }
     return PSSBAM_OK;
 }
 

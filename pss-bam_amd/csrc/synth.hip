@@ -1,0 +1,217 @@
+// pss-bam_amd/csrc/synth.hip -- libpssbam_synth.so: materialises the synthetic workload
+// of synth_model.h on the device (bench.py: straight into HBM) and on the host (tests,
+// CPU-baseline sample: BAM records, SAM text, FASTA).  Workload infrastructure only.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "synth_model.h"
+
+// ---------------------------------------------------------------------------------------
+// device kernels
+// ---------------------------------------------------------------------------------------
+__global__ void k_genome(const synth_cfg c, uint32_t contig, uint8_t *out, uint64_t len) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x * 4u;
+    for (uint64_t p = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4u; p < len; p += stride) {
+        uint32_t w = 0;
+        for (uint32_t k = 0; k < 4 && p + k < len; k++) {
+            const uint32_t b = syn_ref_code(&c, contig, p + k);
+            w |= (uint32_t)(b < 4u ? "ACGT"[b] : 'N') << (8u * k);
+        }
+        if (p + 4 <= len) *(uint32_t *)(out + p) = w;  // out is 4-byte aligned (hipMalloc / torch)
+        else for (uint32_t k = 0; p + k < len; k++) out[p + k] = (uint8_t)(w >> (8u * k));
+    }
+}
+
+__global__ void k_records(const synth_cfg c, uint64_t slot0, uint64_t n, const uint32_t *offs, uint8_t *out) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) {
+        const uint64_t idx = syn_read_index(&c, slot0 + t);
+        synth_read r;
+        syn_read_fields(&c, idx, &r);
+        syn_write_record(&c, idx, &r, out + offs[t]);
+    }
+}
+
+__global__ void k_offsets_linear(uint32_t *offs, uint64_t n_plus_1, uint32_t rec_bytes) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n_plus_1; t += stride)
+        offs[t] = (uint32_t)(t * rec_bytes);
+}
+
+// ---------------------------------------------------------------------------------------
+// helpers
+// ---------------------------------------------------------------------------------------
+template <class F>
+static void parallel_for(uint64_t n, int threads, F f) {
+    if (threads <= 1 || n < 4096) { f(0, n); return; }
+    std::vector<std::thread> th;
+    const uint64_t per = (n + threads - 1) / threads;
+    for (int t = 0; t < threads; t++) {
+        const uint64_t a = std::min<uint64_t>(n, per * t), b = std::min<uint64_t>(n, a + per);
+        if (a < b) th.emplace_back([=] { f(a, b); });
+    }
+    for (auto &x : th) x.join();
+}
+
+static void contig_name(const synth_cfg *c, uint32_t k, char buf[16]) {
+    if (c->name_mode == 0) snprintf(buf, 16, k == 0 ? "chrS" : "chrS%u", k);
+    else if (k < 22) snprintf(buf, 16, "chr%u", k + 1);
+    else if (k == 22) snprintf(buf, 16, "chrX");
+    else if (k == 23) snprintf(buf, 16, "chrY");
+    else snprintf(buf, 16, "chrUn%u", k);
+}
+
+extern "C" {
+
+int synth_cfg_finish(synth_cfg *c) {
+    if (!c || c->n_contigs == 0 || c->n_contigs > SYN_MAX_CONTIGS || c->n_reads == 0 || c->len_min == 0 ||
+        c->len_max < c->len_min)
+        return -1;
+    c->usable_first[0] = 0;
+    for (uint32_t k = 0; k < c->n_contigs; k++) {
+        if (c->contig_len[k] < (uint64_t)c->len_max + 5) return -1;
+        c->usable_first[k + 1] = c->usable_first[k] + (c->contig_len[k] - c->len_max - 4);
+    }
+    uint64_t mul = 0x9E3779B1ull % c->n_reads;
+    if (mul < 2) mul = 1;
+    while (std::gcd(mul, c->n_reads) != 1) mul++;
+    c->perm_mul = mul;
+    c->perm_add = syn_mix(c->seed ^ 0x7065726Dull) % c->n_reads;
+    return 0;
+}
+
+void synth_contig_name(const synth_cfg *c, uint32_t k, char *buf16) { contig_name(c, k, buf16); }
+
+// contig bytes [p0, p0+n) in loaded form (upper case) or, with fasta_case, as FASTA text
+// would hold them (soft-masked lower case)
+int synth_genome_host(const synth_cfg *c, uint32_t contig, uint8_t *out, uint64_t p0, uint64_t n, int fasta_case,
+                      int threads) {
+    parallel_for(n, threads, [=](uint64_t a, uint64_t b) {
+        for (uint64_t i = a; i < b; i++) {
+            const uint32_t code = syn_ref_code(c, contig, p0 + i);
+            uint8_t ch = code < 4u ? (uint8_t)"ACGT"[code] : (uint8_t)'N';
+            if (fasta_case && syn_ref_is_lower(c, contig, p0 + i)) ch |= 0x20;
+            out[i] = ch;
+        }
+    });
+    return 0;
+}
+
+int synth_genome_device(const synth_cfg *c, uint32_t contig, uint8_t *d_out, uint64_t len, void *stream) {
+    hipLaunchKernelGGL(k_genome, dim3(4096), dim3(256), 0, (hipStream_t)stream, *c, contig, d_out, len);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int synth_sizes_host(const synth_cfg *c, uint64_t slot0, uint64_t n, uint32_t *sizes, int threads) {
+    parallel_for(n, threads, [=](uint64_t a, uint64_t b) {
+        for (uint64_t t = a; t < b; t++) {
+            synth_read r;
+            syn_read_fields(c, syn_read_index(c, slot0 + t), &r);
+            sizes[t] = r.rec_bytes;
+        }
+    });
+    return 0;
+}
+
+int synth_records_host(const synth_cfg *c, uint64_t slot0, uint64_t n, const uint32_t *offs, uint8_t *out,
+                       int threads) {
+    parallel_for(n, threads, [=](uint64_t a, uint64_t b) {
+        for (uint64_t t = a; t < b; t++) {
+            const uint64_t idx = syn_read_index(c, slot0 + t);
+            synth_read r;
+            syn_read_fields(c, idx, &r);
+            syn_write_record(c, idx, &r, out + offs[t]);
+        }
+    });
+    return 0;
+}
+
+int synth_records_device(const synth_cfg *c, uint64_t slot0, uint64_t n, const uint32_t *d_offs, uint8_t *d_out,
+                         void *stream) {
+    if (!n) return 0;
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>((n + 255) / 256, 65536);
+    hipLaunchKernelGGL(k_records, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *c, slot0, n, d_offs, d_out);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int synth_offsets_linear_device(uint32_t *d_offs, uint64_t n_plus_1, uint32_t rec_bytes, void *stream) {
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>((n_plus_1 + 255) / 256, 16384);
+    hipLaunchKernelGGL(k_offsets_linear, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_offs, n_plus_1, rec_bytes);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// SAM text of slots [slot0, slot0+n), written from the model's fields directly (NOT by
+// decoding the BAM bytes): the independent text twin the reference binary is fed with.
+int synth_sam_host(const synth_cfg *c, uint64_t slot0, uint64_t n, const char *path, int with_header) {
+    FILE *f = fopen(path, "w");
+    if (!f) return -1;
+    static char iobuf[1 << 20];
+    setvbuf(f, iobuf, _IOFBF, sizeof iobuf);
+    char nm[16];
+    if (with_header) {
+        fputs("@HD\tVN:1.6\tSO:unknown\n", f);
+        for (uint32_t k = 0; k < c->n_contigs; k++) {
+            contig_name(c, k, nm);
+            fprintf(f, "@SQ\tSN:%s\tLN:%llu\n", nm, (unsigned long long)c->contig_len[k]);
+        }
+    }
+    std::string seq, qual;
+    for (uint64_t t = 0; t < n; t++) {
+        const uint64_t idx = syn_read_index(c, slot0 + t);
+        synth_read r;
+        syn_read_fields(c, idx, &r);
+        contig_name(c, r.contig, nm);
+        char cig[64];
+        int o = 0;
+        for (uint32_t k = 0; k < r.n_cigar; k++)
+            o += snprintf(cig + o, sizeof cig - o, "%u%c", r.cigar[k] >> 4, "MIDNSHP=X"[r.cigar[k] & 15u]);
+        seq.resize(r.L);
+        qual.assign(r.L, 'I');
+        for (uint32_t j = 0; j < r.L; j++) {
+            const uint32_t b = syn_read_code(c, idx, &r, j);
+            seq[j] = b < 4u ? "ACGT"[b] : 'N';
+        }
+        fprintf(f, "s%010llu\t%u\t%s\t%llu\t%u\t%s\t*\t0\t0\t%s\t%s\n", (unsigned long long)idx, r.flag, nm,
+                (unsigned long long)(r.s + 1), r.mapq, cig, seq.c_str(), qual.c_str());
+    }
+    return fclose(f) == 0 ? 0 : -1;
+}
+
+// FASTA text (soft-masked) of contigs [first, first+count)
+int synth_fasta_host(const synth_cfg *c, const char *path, uint32_t first, uint32_t count, uint32_t width,
+                     int threads) {
+    FILE *f = fopen(path, "w");
+    if (!f) return -1;
+    static char iobuf[1 << 20];
+    setvbuf(f, iobuf, _IOFBF, sizeof iobuf);
+    const uint64_t CH = 1u << 24;
+    std::vector<uint8_t> buf(CH);
+    std::vector<char> line((size_t)CH + CH / width + 2);
+    char nm[16];
+    for (uint32_t k = first; k < first + count && k < c->n_contigs; k++) {
+        contig_name(c, k, nm);
+        fprintf(f, ">%s synthetic length=%llu\n", nm, (unsigned long long)c->contig_len[k]);
+        uint64_t col = 0;
+        for (uint64_t p0 = 0; p0 < c->contig_len[k]; p0 += CH) {
+            const uint64_t n = std::min<uint64_t>(CH, c->contig_len[k] - p0);
+            synth_genome_host(c, k, buf.data(), p0, n, 1, threads);
+            size_t w = 0;
+            for (uint64_t i = 0; i < n; i++) {
+                line[w++] = (char)buf[i];
+                if (++col == width) { line[w++] = '\n'; col = 0; }
+            }
+            fwrite(line.data(), 1, w, f);
+        }
+        if (col) fputc('\n', f);
+    }
+    return fclose(f) == 0 ? 0 : -1;
+}
+
+}  // extern "C"
