@@ -105,14 +105,16 @@ struct pssbam_engine {
     double kernel_ms = 0.0;
     uint64_t kernel_launches = 0;
     // tuning overrides (environment, for experiments)
-    int env_tile_reads = 0, env_tile_cap = 0, env_grid_mult = 0, env_simple_blocks = 0;
+    int env_tile_reads = 0, env_tile_cap = 0, env_grid_mult = 0, env_simple_blocks = 0, env_stage_bufs = 0;
 };
 
 static void ctx_mask(const char *set, uint32_t (&m)[8]) {
-    // strchr(set, c) != NULL: every byte of the string, plus the terminator itself
+    // strchr(set, c) != NULL: every byte of the string, plus the terminator itself --
+    // expressed over STORED genome bytes (enc_byte permutation, record_decode.h)
     memset(m, 0, sizeof m);
     for (const unsigned char *p = (const unsigned char *)set;; p++) {
-        m[*p >> 5] |= 1u << (*p & 31);
+        const uint32_t st = enc_byte(*p);
+        m[st >> 5] |= 1u << (st & 31);
         if (!*p) break;
     }
 }
@@ -191,6 +193,7 @@ extern "C" int pssbam_engine_create(const pssbam_config *cfg, pssbam_engine **ou
     e->env_tile_cap = env_int("PSSBAM_TILE_CAP");
     e->env_grid_mult = env_int("PSSBAM_GRID_MULT");
     e->env_simple_blocks = env_int("PSSBAM_SIMPLE_BLOCKS");
+    e->env_stage_bufs = env_int("PSSBAM_STAGE_BUFS");
     *out = e;
     return PSSBAM_OK;
 }
@@ -257,13 +260,16 @@ extern "C" int pssbam_engine_set_genome_arrays(pssbam_engine *e, size_t n, const
     if (e->d_contig_start) { HIP_TRY(hipFree(e->d_contig_start)); e->d_contig_start = nullptr; }
     if (e->d_contig_len) { HIP_TRY(hipFree(e->d_contig_len)); e->d_contig_len = nullptr; }
     HIP_TRY(hipMalloc(&e->d_genome, total));
+    // padding = raw NUL, like the terminator the reference finds at index len (fragkon.c odd-k
+    // windows); the encode pass below turns it into the stored form of NUL ("not a base")
     HIP_TRY(hipMemsetAsync(e->d_genome, 0, total, e->stream));
     for (size_t k = 0; k < n; k++) {
         if (!len[k]) continue;
         HIP_TRY(hipMemcpyAsync(e->d_genome + start[k], seqs[order[k]], len[k],
                                seqs_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, e->stream));
     }
-    hipLaunchKernelGGL(upcase_kernel, dim3(2048), dim3(256), 0, e->stream, e->d_genome, total);
+    // raw bytes (and NUL padding) are in place: one pass folds case and applies enc_byte to all
+    hipLaunchKernelGGL(encode_genome_kernel, dim3(4096), dim3(256), 0, e->stream, e->d_genome, total / 16);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMalloc(&e->d_contig_start, (n + 1) * sizeof(uint64_t)));
     HIP_TRY(hipMalloc(&e->d_contig_len, (n + 1) * sizeof(uint64_t)));
@@ -417,15 +423,16 @@ static int launch_tally(pssbam_engine *e, const uint8_t *d_recs, uint64_t nbytes
         // tile geometry from the block's mean record size; records that overflow the
         // staging window are handled (slowly, correctly) straight from global memory
         const uint64_t avg = std::max<uint64_t>(40, nbytes / n_records);
-        uint32_t T = avg * 256 <= 36 * 1024 ? 256u : avg * 128 <= 40 * 1024 ? 128u : 64u;
-        if (e->env_tile_reads > 0) T = (uint32_t)e->env_tile_reads;
-        uint64_t cap64 = (uint64_t)T * avg + (uint64_t)T * avg / 8 + 256;
-        cap64 = std::min<uint64_t>(cap64, 96 * 1024);
+        uint32_t T = avg * 128 <= 40 * 1024 ? 128u : 64u;
+        if (e->env_tile_reads > 0) T = (uint32_t)(e->env_tile_reads + 63) / 64 * 64;
+        uint64_t cap64 = (uint64_t)T * avg + (uint64_t)T * avg / 16 + 512;
+        cap64 = std::min<uint64_t>(cap64, 64 * 1024);
         if (e->env_tile_cap > 0) cap64 = (uint64_t)e->env_tile_cap;
         P.reads_per_tile = T;
-        P.tile_bytes_cap = (uint32_t)((cap64 + 15) & ~15ull);
+        P.tile_bytes_cap = (uint32_t)((cap64 + 1023) & ~1023ull);
+        P.n_stage_bufs = e->env_stage_bufs == 1 ? 1u : 2u;
         const bool kmer_lds = do_kmer && c.kmer.klen <= KMER_LDS_MAX_K;
-        const uint32_t lds = tiled_lds_bytes(T, P.tile_bytes_cap, kmer_lds, c.kmer.klen);
+        const uint32_t lds = tiled_lds_bytes(T, P.tile_bytes_cap, P.n_stage_bufs, kmer_lds, c.kmer.klen);
         const uint32_t n_tiles = (n_records + T - 1) / T;
         int occ = 0, rc = PSSBAM_OK;
         const int mult = e->env_grid_mult > 0 ? e->env_grid_mult : 1;

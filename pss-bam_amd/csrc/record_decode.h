@@ -31,7 +31,7 @@ struct TallyParams {
     const uint32_t *offs;         // n_recs + 1 offsets into recs
     uint32_t n_recs;
     uint32_t tally_mask;          // PSSBAM_TALLY_*
-    const uint8_t *genome;        // all contigs, 1 byte/base, zero padded between
+    const uint8_t *genome;        // all contigs, 1 stored byte/base (enc_byte), padded between
     const uint64_t *contig_start; // per genome contig (sorted-id order)
     const uint64_t *contig_len;
     const int32_t *ref_map;       // BAM refID -> genome contig, -1 = find_seq fails
@@ -42,7 +42,7 @@ struct TallyParams {
     uint32_t pss_min_mq;
     uint64_t pss_min_len, pss_max_len;
     uint32_t pss_merged_only;
-    uint32_t up_mask[8], down_mask[8];  // 256-bit membership sets for strchr(UP_CTX/DOWN_CTX, c)
+    uint32_t up_mask[8], down_mask[8];  // strchr(UP_CTX/DOWN_CTX, c) as 256-bit sets over STORED bytes
     // fragkon options (fragkon.c:14-18)
     int32_t K;
     uint32_t fk_min_mq;
@@ -55,8 +55,9 @@ struct TallyParams {
     unsigned long long *counters;
     uint32_t off_rev, off_k5, off_k3, off_stats;
     // tiled kernel geometry
-    uint32_t reads_per_tile;
-    uint32_t tile_bytes_cap;
+    uint32_t reads_per_tile;      // T, multiple of 64
+    uint32_t tile_bytes_cap;      // bytes of one staging buffer, multiple of 1024
+    uint32_t n_stage_bufs;        // 1 or 2 (2 = next tile's DMA overlaps this tile's tally)
 };
 
 // stats slots, must match include/pssbam_hip.h
@@ -184,20 +185,27 @@ __device__ bool has_read_group(const Src &src, const RecHdr &h, const uint8_t *r
 }
 
 // ---- base codes ----------------------------------------------------------------------
-// genome byte -> A0 C1 G2 T3, 4 = anything else (pss-bam.c:205-251, kmer.c:190-208).
-__device__ __forceinline__ uint32_t ref_code(uint32_t b) {
-    return b == 'A' ? 0u : b == 'C' ? 1u : b == 'G' ? 2u : b == 'T' ? 3u : 4u;
+// Device-internal genome encoding: the byte permutation that swaps 'A'<->0, 'C'<->1,
+// 'G'<->2, 'T'<->3 and leaves every other value where it is (applied once at upload,
+// after the toupper() fold the reference applies at load and again in process_aln,
+// fasta-genome-io.c:127, pss-bam.c:424).  A stored byte < 4 IS the base's 2-bit code
+// (A0 C1 G2 T3: pss-bam.c:205-251 pair order, kmer.c:190-208); anything else is "not
+// ACGT".  It is a bijection, so the -U/-D membership sets are simply permuted the same
+// way on the host and nothing about the original byte is lost.
+__host__ __device__ __forceinline__ uint32_t enc_byte(uint32_t b) {
+    return b == 'A' ? 0u : b == 'C' ? 1u : b == 'G' ? 2u : b == 'T' ? 3u
+         : b == 0u ? 'A' : b == 1u ? 'C' : b == 2u ? 'G' : b == 3u ? 'T' : b;
 }
+__device__ __forceinline__ uint32_t ref_code(uint32_t stored) { return stored < 4u ? stored : 4u; }
 // BAM 4-bit code -> same scale: 1(A) 2(C) 4(G) 8(T); every other code prints as a
 // non-ACGT letter ("=MRSVWYHKDBN") and never matches a pair string.
 __device__ __forceinline__ uint32_t nib_code(uint32_t n) {
-    return n == 1 ? 0u : n == 2 ? 1u : n == 4 ? 2u : n == 8 ? 3u : 4u;
+    // 2-bit entries for n = 1,2,4,8 -> 0,1,2,3 ; validity bitmap 0x0116 = bits 1,2,4,8
+    return ((0x0116u >> n) & 1u) ? ((0x00030210u >> (2u * n)) & 3u) : 4u;
 }
-// one byte of do_revcomp on an upper-case genome byte (pss-bam.c:60-79)
-__device__ __forceinline__ uint32_t comp_byte(uint32_t b) {
-    return b == 'A' ? 'T' : b == 'C' ? 'G' : b == 'G' ? 'C' : b == 'T' ? 'A'
-         : b == 'a' ? 'T' : b == 'c' ? 'G' : b == 'g' ? 'C' : b == 't' ? 'A' : b;
-}
+// one byte of do_revcomp (pss-bam.c:60-79) on a stored (encoded, upper-case) genome byte:
+// ACGT complement, everything else unchanged
+__device__ __forceinline__ uint32_t comp_stored(uint32_t stored) { return stored < 4u ? 3u - stored : stored; }
 __device__ __forceinline__ bool in_set(const uint32_t (&m)[8], uint32_t b) { return (m[(b >> 5) & 7] >> (b & 31)) & 1u; }
 
 template <class Src>
@@ -266,8 +274,8 @@ __device__ Plan make_plan(const TallyParams &P, const Src &src, const RecHdr &h)
         ok = ok && !(h.flag & FL_REJECT) && !(P.pss_merged_only && paired);
         if (ok) {
             // first context base each side, in read orientation (pss-bam.c:134-142, :461, :472)
-            const uint32_t up = pl.rev ? comp_byte(G[pl.s + L]) : G[pl.s - 1];
-            const uint32_t dn = pl.rev ? comp_byte(G[pl.s - 1]) : G[pl.s + L];
+            const uint32_t up = pl.rev ? comp_stored(G[pl.s + L]) : G[pl.s - 1];
+            const uint32_t dn = pl.rev ? comp_stored(G[pl.s - 1]) : G[pl.s + L];
             const bool up_ok = in_set(P.up_mask, up), dn_ok = in_set(P.down_mask, dn);
             if (!paired) {
                 pl.pss_fwd = pl.pss_rev = up_ok && dn_ok;                       // :428-447

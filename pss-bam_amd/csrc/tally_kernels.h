@@ -3,17 +3,27 @@
 //  tally_simple : lane-per-read, records and reference bases gathered straight from
 //                 global memory, counts into an LDS table (or global atomics when the
 //                 table would not fit).  Any -r N, any k.  Fallback + cross-check.
-//  tally_tiled  : the production kernel for N <= 30.  Per tile of T consecutive reads:
-//                   1. the tile's raw BAM bytes are streamed into LDS with 16 B/lane
-//                      coalesced loads (the only bulk HBM traffic of the kernel);
-//                   2. lane-per-read: decode + filters, gather the two reference end
-//                      windows (s-2..s+N, s+L-N..s+L+2) into LDS, k-mer tally;
-//                   3. wave-per-read, lane = table row: lanes 0..31 own the forward
-//                      table's rows, lanes 32..63 the reverse table's rows; each lane
-//                      forms its (read base, reference base) cell and bumps its own
-//                      column of a [16][64] LDS table -- no two lanes of a wave ever
-//                      touch the same word, so there is no intra-wave contention no
-//                      matter how skewed the data (AA/CC/GG/TT dominate).
+//  tally_tiled  : the production kernel for N <= 30.  Persistent workgroups walk tiles
+//                 of T consecutive reads:
+//                   1. STAGE   the tile's raw BAM bytes are streamed into LDS by LDS-DMA
+//                              (global_load_lds_dwordx4: 1 KiB per wave-instruction, no
+//                              VGPR round trip); with two staging buffers the next tile's
+//                              DMA is in flight while this tile is decoded and tallied.
+//                              This is the only bulk HBM traffic of the kernel.
+//                   2. CODES   a lane pair per read (one lane per alignment end): decode
+//                              + filters from LDS, gather the end's reference window
+//                              (N+2 bytes) from the device genome, turn the N+2 positions
+//                              into one byte each = (cell << 1 | table) or 0xFF, through a
+//                              272-byte LDS lookup table indexed by (read nibble,
+//                              reference code, strand), and store the 2 x 32 bytes of the
+//                              read's row of the code sheet.  K-mer windows are tallied
+//                              here too (one per lane of the pair).
+//                   3. COLUMNS wave-per-read, lane = column of the code sheet: each lane
+//                              owns one (end, position) and bumps ITS word of a
+//                              [cell,table][row] LDS table.  Lanes of one wave-instruction
+//                              never share a word and the two 32-lane halves hit disjoint
+//                              banks, so the AA/CC/GG/TT skew of real data causes no
+//                              serialisation at all.
 //                 Counters leave LDS once, at kernel end, as u64 global atomics.
 //
 // Integer/byte work only: no MFMA anywhere (the bound is HBM bandwidth).
@@ -24,12 +34,15 @@
 namespace pssbam {
 
 constexpr int TILED_THREADS = 256;
-constexpr int TILED_MAX_N = 30;        // 2*(N+2) rows must fit the 64 lanes of a wave
+constexpr int TILED_WAVES = TILED_THREADS / 64;
+constexpr int TILED_MAX_N = 30;        // N+2 positions per end must fit 32 lanes
 constexpr int WIN_DWORDS = 9;          // (N+2) + 3 alignment bytes <= 36
 constexpr int KMER_LDS_MAX_K = 5;      // 2 * 4^5 * 4 B = 8 KiB of LDS
+constexpr uint32_t STAGE_SLACK = 64;   // readable bytes behind a staging buffer
+constexpr uint32_t PAIR_LUT_BYTES = 2 * 17 * 8;
 
 // ---------------------------------------------------------------------------------------
-// per-read tally, lane-per-read form (used by tally_simple and for tile overflow records)
+// per-read tally, lane-per-read form (tally_simple, and tile-overflow records)
 // ---------------------------------------------------------------------------------------
 struct LdsTableRowMajor {  // [table][row][16] u32 in LDS
     uint32_t *t;
@@ -38,10 +51,10 @@ struct LdsTableRowMajor {  // [table][row][16] u32 in LDS
         atomicAdd(&t[(table * rows + row) * 16u + cell], 1u);
     }
 };
-struct LdsTableLaneMajor {  // [cell][lane] u32 in LDS, lane = table*32 + row (tiled kernel)
+struct LdsTableColumnMajor {  // [(cell << 1) | table][32 rows] u32 in LDS (tiled kernel)
     uint32_t *t;
     __device__ __forceinline__ void add(uint32_t table, uint32_t row, uint32_t cell) const {
-        atomicAdd(&t[cell * 64u + table * 32u + row], 1u);
+        atomicAdd(&t[(((cell << 1) | table) << 5) + row], 1u);
     }
 };
 struct GlobalTable {  // straight into the u64 counter block
@@ -84,28 +97,26 @@ __device__ __forceinline__ void tally_pss_record(const TallyParams &P, const Tab
     if (pl.pss_rev) tally_end(tab, 1u, src, h, G, pl.s, pl.L, P.N, pl.rev, pl.rev);
 }
 
-// k-mer adds for one record; returns the stats bit (OK / FAIL) it earns.
+// one k-mer add (5' when which == 0, 3' when which == 1); false = non-ACGT in the window
 template <bool LDS_KMER>
-__device__ __forceinline__ uint32_t tally_kmer_record(const TallyParams &P, const Plan &pl, uint32_t *lds_kmer) {
+__device__ __forceinline__ bool tally_one_kmer(const TallyParams &P, const Plan &pl, uint32_t which, uint32_t *lds_kmer) {
     const uint8_t *G = P.genome + pl.gbase;
     int64_t w5, w3;
     kmer_windows(pl, P.K, w5, w3);
-    const uint32_t nb = 1u << (2 * P.K);
+    uint32_t bin;
+    if (!kmer_bin(G, which ? w3 : w5, P.K, pl.rev, bin)) return false;
+    if (LDS_KMER) atomicAdd(&lds_kmer[(which ? (1u << (2 * P.K)) : 0u) + bin], 1u);
+    else atomicAdd(&P.counters[(which ? P.off_k3 : P.off_k5) + bin], 1ull);
+    return true;
+}
+
+// both k-mer adds of one record; returns the stats bit (OK / FAIL) it earns
+// (fragkon.c:164-181: both attempted, 0 only if both succeeded; :198-210 single add)
+template <bool LDS_KMER>
+__device__ __forceinline__ uint32_t tally_kmer_record(const TallyParams &P, const Plan &pl, uint32_t *lds_kmer) {
     bool good = true;
-    if (pl.fk5) {
-        uint32_t bin;
-        if (kmer_bin(G, w5, P.K, pl.rev, bin)) {
-            if (LDS_KMER) atomicAdd(&lds_kmer[bin], 1u);
-            else atomicAdd(&P.counters[P.off_k5 + bin], 1ull);
-        } else good = false;
-    }
-    if (pl.fk3) {
-        uint32_t bin;
-        if (kmer_bin(G, w3, P.K, pl.rev, bin)) {
-            if (LDS_KMER) atomicAdd(&lds_kmer[nb + bin], 1u);
-            else atomicAdd(&P.counters[P.off_k3 + bin], 1ull);
-        } else good = false;
-    }
+    if (pl.fk5) good = tally_one_kmer<LDS_KMER>(P, pl, 0u, lds_kmer) && good;
+    if (pl.fk3) good = tally_one_kmer<LDS_KMER>(P, pl, 1u, lds_kmer) && good;
     return good ? (1u << ST_KMER_OK) : (1u << ST_KMER_FAIL);
 }
 
@@ -166,26 +177,31 @@ __global__ void __launch_bounds__(256) tally_simple(const TallyParams P) {
 // ---------------------------------------------------------------------------------------
 // tally_tiled
 // ---------------------------------------------------------------------------------------
-// Per-read descriptor handed from phase 2 to phase 3 (16 bytes, read with one broadcast
-// ds_read_b128 per wave).
-struct __attribute__((aligned(16))) ReadDesc {
-    uint32_t seq_off;  // offset of SEQ inside the staged tile
-    uint32_t L;        // effective length
-    uint32_t l_seq;    // bases really present
-    uint32_t flags;    // bit0 fwd table, bit1 rev table, bit2 reverse strand, bits 8..9 left shift,
-                       // bits 16..17 right shift
-};
-
 // dynamic LDS carve-up (all 16-byte aligned):
-//   stage  : tile_bytes_cap + 16
-//   desc   : T * 16
-//   gwin   : T * 2 * WIN_DWORDS * 4
-//   table  : 16 * 64 * 4
-//   kmer   : 2 * 4^K * 4        (only when K <= KMER_LDS_MAX_K and the k-mer tally is on)
-__host__ __device__ inline uint32_t tiled_lds_bytes(uint32_t T, uint32_t cap, bool kmer_lds, int K) {
-    uint32_t b = ((cap + 16u + 15u) & ~15u) + T * 16u + T * 2u * WIN_DWORDS * 4u + 16u * 64u * 4u;
+//   stage[n_bufs] : tile_bytes_cap + STAGE_SLACK each   raw BAM bytes of a tile
+//   sheet         : T * 64                               code sheet [read][end*32 + position]
+//   table         : 32 * 32 * 4                          [(cell<<1)|table][row] u32
+//   lut           : PAIR_LUT_BYTES (padded to 16)        (strand, nibble row, ref code) -> code
+//   kmer          : 2 * 4^K * 4   (only when K <= KMER_LDS_MAX_K and the k-mer tally is on)
+__host__ __device__ inline uint32_t tiled_stage_stride(uint32_t cap) { return (cap + STAGE_SLACK + 15u) & ~15u; }
+__host__ __device__ inline uint32_t tiled_lds_bytes(uint32_t T, uint32_t cap, uint32_t n_bufs, bool kmer_lds, int K) {
+    uint32_t b = n_bufs * tiled_stage_stride(cap) + T * 64u + 32u * 32u * 4u + ((PAIR_LUT_BYTES + 15u) & ~15u);
     if (kmer_lds) b += 2u * (1u << (2 * K)) * 4u;
     return b;
+}
+
+// Streams bytes [base16, base16 + nbytes) of the record block into `stage` (nbytes is a
+// multiple of 16; the tail chunk is lane-predicated so nothing beyond it is read).
+__device__ __forceinline__ void stage_tile_dma(const uint8_t *recs, uint32_t base16, uint32_t nbytes, uint8_t *stage,
+                                               uint32_t wave, uint32_t lane) {
+    const uint32_t n_chunks = (nbytes + 1023u) >> 10;
+    for (uint32_t c = wave; c < n_chunks; c += TILED_WAVES) {
+        const uint32_t off = (c << 10) + (lane << 4);
+        if (off < nbytes) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(recs + base16 + off),
+                                             (__attribute__((address_space(3))) void *)(stage + (c << 10)), 16, 0, 0);
+        }
+    }
 }
 
 template <bool DO_PSS, bool DO_KMER, bool LDS_KMER>
@@ -195,124 +211,201 @@ __global__ void __launch_bounds__(TILED_THREADS) tally_tiled(const TallyParams P
 
     const uint32_t T = P.reads_per_tile;
     const uint32_t cap = P.tile_bytes_cap;
-    uint8_t *stage = lds_raw;
-    ReadDesc *desc = (ReadDesc *)(lds_raw + ((cap + 16u + 15u) & ~15u));
-    uint32_t *gwin = (uint32_t *)(desc + T);
-    uint32_t *table = gwin + T * 2u * WIN_DWORDS;
-    uint32_t *lds_kmer = table + 16u * 64u;
+    const uint32_t n_bufs = P.n_stage_bufs;
+    const uint32_t stage_stride = tiled_stage_stride(cap);
+    uint8_t *stage0 = lds_raw;
+    uint8_t *sheet = lds_raw + n_bufs * stage_stride;
+    uint32_t *table = (uint32_t *)(sheet + T * 64u);
+    uint8_t *lut = (uint8_t *)(table + 32u * 32u);
+    uint32_t *lds_kmer = (uint32_t *)(lut + ((PAIR_LUT_BYTES + 15u) & ~15u));
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u, wave = tid >> 6;
     const int N = P.N;
-    const uint32_t win_dw = ((uint32_t)N + 5u + 3u) >> 2;  // dwords covering (N+2) bytes at any shift
+    const uint32_t n_pos = (uint32_t)N + 2u;                 // positions per end: 2 context + N
+    const uint32_t win_dw = ((uint32_t)N + 5u + 3u) >> 2;    // dwords covering n_pos bytes at any shift
 
-    for (uint32_t i = tid; i < 16u * 64u; i += TILED_THREADS) table[i] = 0u;
+    // ---- one-time set-up: zero the tables, build the pair LUT ---------------------------------
+    for (uint32_t i = tid; i < 32u * 32u; i += TILED_THREADS) table[i] = 0u;
     if (LDS_KMER)
         for (uint32_t i = tid; i < 2u * (1u << (2 * P.K)); i += TILED_THREADS) lds_kmer[i] = 0u;
     if (tid < ST_USED) lds_stats[tid] = 0u;
+    for (uint32_t i = tid; i < PAIR_LUT_BYTES; i += TILED_THREADS) {
+        // index = strand*136 + row*8 + g ; row 0..15 = read nibble, row 16 = context position
+        // (cell of a context base is the diagonal one, pss-bam.c:172-184); g = min(stored, 4)
+        const uint32_t strand = i / 136u, row = (i % 136u) >> 3, g = i & 7u;
+        const uint32_t rd = row == 16u ? g : nib_code(row);
+        uint32_t v = 0xFFu;
+        if (g < 4u && rd < 4u) {
+            const uint32_t cell = 4u * rd + g;
+            v = (strand ? 15u - cell : cell) << 1;  // bit 0 (table) is OR-ed in per read
+        }
+        lut[i] = (uint8_t)v;
+    }
 
     uint32_t my_stats[ST_USED];
 #pragma unroll
     for (int i = 0; i < ST_USED; i++) my_stats[i] = 0u;
 
     const uint32_t n_tiles = (P.n_recs + T - 1u) / T;
-    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const uint32_t r0 = tile * T;
-        const uint32_t r1 = min(r0 + T, P.n_recs);
+    uint32_t tile = blockIdx.x;
+    // geometry of a tile's byte range
+    auto tile_range = [&](uint32_t t, uint32_t &base16, uint32_t &staged) {
+        const uint32_t r0 = t * T, r1 = min(r0 + T, P.n_recs);
         const uint32_t o_first = P.offs[r0], o_last = P.offs[r1];
-        const uint32_t base16 = o_first & ~15u;
-        const uint32_t want = o_last - base16;
-        const uint32_t staged = min(want, cap);  // bytes [base16, base16+staged) are in LDS
+        base16 = o_first & ~15u;
+        staged = min((o_last - base16 + 15u) & ~15u, cap);
+    };
+    uint32_t base16 = 0, staged = 0;
+    if (tile < n_tiles) {
+        tile_range(tile, base16, staged);
+        stage_tile_dma(P.recs, base16, staged, stage0, wave, lane);
+    }
 
-        __syncthreads();  // previous tile fully consumed (also orders the table/kmer zeroing)
-        // ---- phase 1: coalesced stream of the tile's record bytes into LDS ----------------
-        {
-            const uint4 *g = (const uint4 *)(P.recs + base16);
-            uint4 *l = (uint4 *)stage;
-            const uint32_t n16 = (staged + 15u) >> 4;
-            uint32_t c = tid;
-            for (; c + 3u * TILED_THREADS < n16; c += 4u * TILED_THREADS) {
-                const uint4 v0 = g[c], v1 = g[c + TILED_THREADS], v2 = g[c + 2u * TILED_THREADS],
-                            v3 = g[c + 3u * TILED_THREADS];
-                l[c] = v0; l[c + TILED_THREADS] = v1; l[c + 2u * TILED_THREADS] = v2; l[c + 3u * TILED_THREADS] = v3;
-            }
-            for (; c < n16; c += TILED_THREADS) l[c] = g[c];
+    for (uint32_t it = 0; tile < n_tiles; tile += gridDim.x, it++) {
+        const uint32_t cur = (n_bufs == 2u) ? (it & 1u) : 0u;
+        uint8_t *stage = stage0 + cur * stage_stride;
+        const uint32_t r0 = tile * T;
+        const uint32_t count = min(T, P.n_recs - r0);
+
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces have landed
+        __syncthreads();                                    // ... everyone's; previous COLUMNS pass is over
+
+        const uint32_t next = tile + gridDim.x;
+        uint32_t nbase16 = 0, nstaged = 0;
+        if (n_bufs == 2u && next < n_tiles) {               // prefetch the next tile behind the compute
+            tile_range(next, nbase16, nstaged);
+            stage_tile_dma(P.recs, nbase16, nstaged, stage0 + (cur ^ 1u) * stage_stride, wave, lane);
         }
-        __syncthreads();
 
-        // ---- phase 2: lane-per-read decode, filters, reference windows, k-mers -----------
-        for (uint32_t j = tid; j < r1 - r0; j += TILED_THREADS) {
-            const uint32_t r = r0 + j;
-            const uint32_t o0 = P.offs[r], o1 = P.offs[r + 1];
-            ReadDesc d;
-            d.seq_off = 0; d.L = 0; d.l_seq = 0; d.flags = 0;
-            uint32_t m;
-            if (o1 - base16 <= staged) {
-                LdsBytes src{stage + (o0 - base16)};
-                const RecHdr h = decode_hdr(src, o1 - o0);
-                const Plan pl = make_plan(P, src, h);
-                m = pl.st_mask;
-                if (DO_PSS && (pl.pss_fwd || pl.pss_rev)) {
-                    const uint64_t ga = pl.gbase + (uint64_t)pl.s - 2u;              // left window start
-                    const uint64_t gb = pl.gbase + (uint64_t)pl.s + pl.L - (uint32_t)N;  // right window start
-                    const uint32_t *pa = (const uint32_t *)(P.genome + (ga & ~3ull));
-                    const uint32_t *pb = (const uint32_t *)(P.genome + (gb & ~3ull));
-                    uint32_t *wl = gwin + (j * 2u) * WIN_DWORDS, *wr = wl + WIN_DWORDS;
-                    for (uint32_t k = 0; k < win_dw; k++) { wl[k] = pa[k]; wr[k] = pb[k]; }
-                    d.seq_off = (o0 - base16) + h.seq_off;
-                    d.L = pl.L;
-                    d.l_seq = h.l_seq;
-                    d.flags = (pl.pss_fwd ? 1u : 0u) | (pl.pss_rev ? 2u : 0u) | (pl.rev ? 4u : 0u) |
-                              ((uint32_t)(ga & 3ull) << 8) | ((uint32_t)(gb & 3ull) << 16);
-                }
-                if (DO_KMER && (pl.fk5 || pl.fk3)) m |= tally_kmer_record<LDS_KMER>(P, pl, lds_kmer);
-            } else {
-                // record does not fit the staging window (huge record): whole thing from global
-                GlobalBytes src{P.recs + o0};
-                const RecHdr h = decode_hdr(src, o1 - o0);
-                const Plan pl = make_plan(P, src, h);
-                m = pl.st_mask;
-                if (DO_PSS && (pl.pss_fwd || pl.pss_rev)) tally_pss_record(P, LdsTableLaneMajor{table}, src, h, pl);
-                if (DO_KMER && (pl.fk5 || pl.fk3)) m |= tally_kmer_record<LDS_KMER>(P, pl, lds_kmer);
-            }
-            desc[j] = d;
+        // ---- CODES: lane pair per read ------------------------------------------------------
+        for (uint32_t p = tid; p < 2u * T; p += TILED_THREADS) {
+            const uint32_t j = p >> 1, e = p & 1u;  // e = 0: left alignment end, 1: right end
+            uint32_t code_w[8];
 #pragma unroll
-            for (int i = 0; i < ST_USED; i++) my_stats[i] += (m >> i) & 1u;
-        }
-        __syncthreads();
-
-        // ---- phase 3: wave-per-read, lane = table row --------------------------------------
-        if (DO_PSS) {
-            const uint32_t t = lane >> 5;       // 0 = forward table, 1 = reverse table
-            const uint32_t row = lane & 31u;    // 0,1 context rows; 2+i = position i
-            const bool row_live = row < (uint32_t)N + 2u;
-            for (uint32_t j = wave; j < r1 - r0; j += TILED_THREADS / 64) {
-                const ReadDesc d = desc[j];
-                if (!((d.flags >> t) & 1u) || !row_live) continue;
-                const bool rev = (d.flags & 4u) != 0;
-                const bool left = (t == 0u) != rev;
-                const uint8_t *w = (const uint8_t *)(gwin + (j * 2u + (left ? 0u : 1u)) * WIN_DWORDS);
-                const uint32_t shift = left ? ((d.flags >> 8) & 3u) : ((d.flags >> 16) & 3u);
-                // left window byte k <-> reference s-2+k; right window byte k <-> s+L-N+k
-                const uint32_t rf = ref_code(w[shift + (left ? row : (uint32_t)N + 1u - row)]);
-                uint32_t cell;
-                bool ok = rf < 4u;
-                if (row < 2u) {
-                    cell = 5u * rf;
-                } else {
-                    const uint32_t ri = left ? row - 2u : d.L + 1u - row;
-                    uint32_t nib = 0u;
-                    if (ri < d.l_seq) {
-                        const uint32_t b = stage[d.seq_off + (ri >> 1)];
-                        nib = (ri & 1u) ? (b & 0xFu) : (b >> 4);
+            for (int k = 0; k < 8; k++) code_w[k] = 0xFFFFFFFFu;
+            uint32_t m = 0u;
+            bool kmer_try = false, kmer_ok = true;
+            if (j < count) {
+                const uint32_t r = r0 + j;
+                const uint32_t o0 = P.offs[r], o1 = P.offs[r + 1];
+                if (o1 - base16 <= staged) {
+                    LdsBytes src{stage + (o0 - base16)};
+                    const RecHdr h = decode_hdr(src, o1 - o0);
+                    const Plan pl = make_plan(P, src, h);
+                    m = pl.st_mask;
+                    // this lane's end feeds: left -> fwd table on forward reads, rev table on reverse reads
+                    const uint32_t tsel = e ^ (pl.rev ? 1u : 0u);
+                    if (DO_PSS && (tsel ? pl.pss_rev : pl.pss_fwd)) {
+                        // reference window of this end: left = s-2 .. s+N-1, right = s+L-N .. s+L+1
+                        const uint64_t ga = pl.gbase + (uint64_t)pl.s + (e ? (uint64_t)pl.L - (uint32_t)N : (uint64_t)-2ll);
+                        const uint32_t *pg = (const uint32_t *)(P.genome + (ga & ~3ull));
+                        uint32_t gw[WIN_DWORDS];
+#pragma unroll
+                        for (int k = 0; k < WIN_DWORDS; k++) gw[k] = (uint32_t)k < win_dw ? pg[k] : 0u;
+                        const uint32_t gsh = (uint32_t)(ga & 3ull);
+#pragma unroll
+                        for (int k = 0; k < WIN_DWORDS - 1; k++) gw[k] = __builtin_amdgcn_alignbyte(gw[k + 1], gw[k], gsh);
+                        // read bases of this end as a nibble stream: stream nibble q <-> read base n0 + q,
+                        // n0 = 0 (left) or L-N (right); position b uses q = b-2 (left, b >= 2) or b (right, b < N)
+                        const uint32_t n0 = e ? pl.L - (uint32_t)N : 0u;
+                        const uint32_t sb = h.seq_off + (n0 >> 1);
+                        uint32_t sw[5];
+#pragma unroll
+                        for (int k = 0; k < 5; k++) sw[k] = src.u32(sb + 4u * k);
+#pragma unroll
+                        for (int k = 0; k < 5; k++)  // high nibble first -> nibble q at bits 4q
+                            sw[k] = ((sw[k] & 0x0F0F0F0Fu) << 4) | ((sw[k] >> 4) & 0x0F0F0F0Fu);
+                        if (n0 & 1u) {
+#pragma unroll
+                            for (int k = 0; k < 4; k++) sw[k] = (sw[k] >> 4) | (sw[k + 1] << 28);
+                        }
+                        // bases at or beyond l_seq do not exist (precondition P3): blank them
+                        const uint32_t have = h.l_seq > n0 ? min(h.l_seq - n0, 32u) : 0u;
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const uint32_t lo = 8u * k;
+                            const uint32_t keep = have >= lo + 8u ? 0xFFFFFFFFu
+                                                 : have > lo ? ((1u << (4u * (have - lo))) - 1u) : 0u;
+                            sw[k] &= keep;
+                        }
+                        const uint8_t *lut_s = lut + (pl.rev ? 136u : 0u);
+#pragma unroll
+                        for (int b = 0; b < 32; b++) {
+                            if ((uint32_t)b < n_pos) {
+                                const uint32_t g = min((gw[b >> 2] >> (8 * (b & 3))) & 0xFFu, 4u);
+                                // context positions: left b < 2, right b >= N
+                                const bool ctx = e ? ((uint32_t)b >= (uint32_t)N) : (b < 2);
+                                const int q = e ? b : b - 2;
+                                const uint32_t nib = (q >= 0 && q < 32) ? (sw[(q >> 3) & 3] >> (4 * (q & 7))) & 0xFu : 0u;
+                                const uint32_t v = lut_s[(ctx ? 16u : nib) * 8u + g];
+                                const uint32_t cb = v == 0xFFu ? 0xFFu : (v | tsel);
+                                code_w[b >> 2] = (code_w[b >> 2] & ~(0xFFu << (8 * (b & 3)))) | (cb << (8 * (b & 3)));
+                            }
+                        }
                     }
-                    const uint32_t rd = nib_code(nib);
-                    ok = ok && rd < 4u;
-                    cell = 4u * rd + rf;
+                    if (DO_KMER && (e ? pl.fk3 : pl.fk5)) {
+                        kmer_try = true;
+                        kmer_ok = tally_one_kmer<LDS_KMER>(P, pl, e, lds_kmer);
+                    }
+                } else if (e == 0u) {
+                    // record does not fit the staging window (huge record): whole thing from global,
+                    // by the first lane of the pair
+                    GlobalBytes src{P.recs + o0};
+                    const RecHdr h = decode_hdr(src, o1 - o0);
+                    const Plan pl = make_plan(P, src, h);
+                    m = pl.st_mask;
+                    if (DO_PSS && (pl.pss_fwd || pl.pss_rev)) tally_pss_record(P, LdsTableColumnMajor{table}, src, h, pl);
+                    if (DO_KMER && (pl.fk5 || pl.fk3)) m |= tally_kmer_record<LDS_KMER>(P, pl, lds_kmer);
                 }
-                if (ok) atomicAdd(&table[(rev ? 15u - cell : cell) * 64u + lane], 1u);
+            }
+            // code sheet row of read j: bytes [e*32, e*32+32)
+            uint4 *dst = (uint4 *)(sheet + j * 64u + e * 32u);
+            dst[0] = make_uint4(code_w[0], code_w[1], code_w[2], code_w[3]);
+            dst[1] = make_uint4(code_w[4], code_w[5], code_w[6], code_w[7]);
+            if (DO_KMER) {
+                // fragkon status of the read = AND over the adds that were attempted (both lanes)
+                const int tried = (kmer_try ? 1 : 0), good = (kmer_ok ? 1 : 0);
+                const int tried_o = __shfl_xor(tried, 1), good_o = __shfl_xor(good, 1);
+                if (e == 0u && (tried || tried_o))
+                    m |= (good && good_o) ? (1u << ST_KMER_OK) : (1u << ST_KMER_FAIL);
+            }
+            if (e == 0u) {
+#pragma unroll
+                for (int i = 0; i < ST_USED; i++) my_stats[i] += (m >> i) & 1u;
             }
         }
+        __syncthreads();
+        if (n_bufs == 1u && next < n_tiles) {
+            // single staging buffer: every wave is past CODES (the only reader of `stage`), so the
+            // next tile's DMA can already run behind the COLUMNS pass
+            tile_range(next, base16, staged);
+            stage_tile_dma(P.recs, base16, staged, stage0, wave, lane);
+        }
+
+        // ---- COLUMNS: wave-per-read, lane = (end, position) --------------------------------------
+        if (DO_PSS) {
+            const uint32_t e = lane >> 5, b = lane & 31u;
+            const uint32_t row = e ? (uint32_t)N + 1u - b : b;   // position -> table row (0,1 context; 2+i)
+            const uint32_t per_wave = (count + TILED_WAVES - 1u) / TILED_WAVES;
+            const uint32_t j0 = wave * per_wave, j1 = min(count, j0 + per_wave);
+            if (b < n_pos) {
+                uint32_t j = j0;
+                for (; j + 8u <= j1; j += 8u) {
+                    uint32_t c[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) c[u] = sheet[(j + u) * 64u + lane];
+#pragma unroll
+                    for (int u = 0; u < 8; u++)
+                        if (c[u] != 0xFFu) atomicAdd(&table[(c[u] << 5) + row], 1u);
+                }
+                for (; j < j1; j++) {
+                    const uint32_t c = sheet[j * 64u + lane];
+                    if (c != 0xFFu) atomicAdd(&table[(c << 5) + row], 1u);
+                }
+            }
+        }
+        if (n_bufs == 2u) { base16 = nbase16; staged = nstaged; }
     }
 
 #pragma unroll
@@ -320,10 +413,10 @@ __global__ void __launch_bounds__(TILED_THREADS) tally_tiled(const TallyParams P
         if (my_stats[i]) atomicAdd(&lds_stats[i], my_stats[i]);
     __syncthreads();
     if (DO_PSS) {
-        for (uint32_t i = tid; i < 16u * 64u; i += TILED_THREADS) {
+        for (uint32_t i = tid; i < 32u * 32u; i += TILED_THREADS) {
             const uint32_t v = table[i];
-            const uint32_t cell = i >> 6, ln = i & 63u, t = ln >> 5, row = ln & 31u;
-            if (v && row < (uint32_t)N + 2u)
+            const uint32_t row = i & 31u, ct = i >> 5, t = ct & 1u, cell = ct >> 1;
+            if (v && row < n_pos)
                 atomicAdd(&P.counters[(t ? P.off_rev : 0u) + row * 16u + cell], (unsigned long long)v);
         }
     }
@@ -337,13 +430,27 @@ __global__ void __launch_bounds__(TILED_THREADS) tally_tiled(const TallyParams P
     flush_stats(P, lds_stats);
 }
 
-// upper-cases a-z in place: init_genome stores toupper()ed bases (fasta-genome-io.c:127)
-// and process_aln folds again (pss-bam.c:424); callers handing raw arrays get the same.
-__global__ void upcase_kernel(uint8_t *p, uint64_t n) {
+// Upload-time genome transform: toupper() fold (init_genome stores upper case,
+// fasta-genome-io.c:127; process_aln folds again, pss-bam.c:424) followed by the
+// A/C/G/T <-> 0..3 byte swap of record_decode.h.  16 bytes per lane per step.
+__global__ void encode_genome_kernel(uint8_t *p, uint64_t n16) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const uint8_t c = p[i];
-        if (c >= 'a' && c <= 'z') p[i] = c - 32;
+    uint4 *q = (uint4 *)p;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) {
+        uint4 v = q[i];
+        uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            uint32_t o = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                uint32_t c = (w[k] >> (8 * b)) & 0xFFu;
+                if (c >= 'a' && c <= 'z') c -= 32u;
+                o |= enc_byte(c) << (8 * b);
+            }
+            w[k] = o;
+        }
+        q[i] = make_uint4(w[0], w[1], w[2], w[3]);
     }
 }
 
