@@ -105,7 +105,7 @@ struct pssbam_engine {
     double kernel_ms = 0.0;
     uint64_t kernel_launches = 0;
     // tuning overrides (environment, for experiments)
-    int env_tile_reads = 0, env_tile_cap = 0, env_grid_mult = 0, env_simple_blocks = 0, env_stage_bufs = 0;
+    int env_tile_reads = 0, env_tile_cap = 0, env_grid_mult = 0, env_simple_blocks = 0;
 };
 
 static void ctx_mask(const char *set, uint32_t (&m)[8]) {
@@ -193,7 +193,6 @@ extern "C" int pssbam_engine_create(const pssbam_config *cfg, pssbam_engine **ou
     e->env_tile_cap = env_int("PSSBAM_TILE_CAP");
     e->env_grid_mult = env_int("PSSBAM_GRID_MULT");
     e->env_simple_blocks = env_int("PSSBAM_SIMPLE_BLOCKS");
-    e->env_stage_bufs = env_int("PSSBAM_STAGE_BUFS");
     *out = e;
     return PSSBAM_OK;
 }
@@ -424,15 +423,14 @@ static int launch_tally(pssbam_engine *e, const uint8_t *d_recs, uint64_t nbytes
         // staging window are handled (slowly, correctly) straight from global memory
         const uint64_t avg = std::max<uint64_t>(40, nbytes / n_records);
         uint32_t T = avg * 128 <= 40 * 1024 ? 128u : 64u;
-        if (e->env_tile_reads > 0) T = (uint32_t)(e->env_tile_reads + 63) / 64 * 64;
+        if (e->env_tile_reads > 0) T = std::min<uint32_t>(512u, (uint32_t)(e->env_tile_reads + 63) / 64 * 64);
         uint64_t cap64 = (uint64_t)T * avg + (uint64_t)T * avg / 16 + 512;
         cap64 = std::min<uint64_t>(cap64, 64 * 1024);
         if (e->env_tile_cap > 0) cap64 = (uint64_t)e->env_tile_cap;
         P.reads_per_tile = T;
         P.tile_bytes_cap = (uint32_t)((cap64 + 1023) & ~1023ull);
-        P.n_stage_bufs = e->env_stage_bufs == 1 ? 1u : 2u;
         const bool kmer_lds = do_kmer && c.kmer.klen <= KMER_LDS_MAX_K;
-        const uint32_t lds = tiled_lds_bytes(T, P.tile_bytes_cap, P.n_stage_bufs, kmer_lds, c.kmer.klen);
+        const uint32_t lds = tiled_lds_bytes(T, P.tile_bytes_cap, kmer_lds, c.kmer.klen);
         const uint32_t n_tiles = (n_records + T - 1) / T;
         int occ = 0, rc = PSSBAM_OK;
         const int mult = e->env_grid_mult > 0 ? e->env_grid_mult : 1;

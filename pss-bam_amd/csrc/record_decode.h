@@ -56,8 +56,7 @@ struct TallyParams {
     uint32_t off_rev, off_k5, off_k3, off_stats;
     // tiled kernel geometry
     uint32_t reads_per_tile;      // T, multiple of 64
-    uint32_t tile_bytes_cap;      // bytes of one staging buffer, multiple of 1024
-    uint32_t n_stage_bufs;        // 1 or 2 (2 = next tile's DMA overlaps this tile's tally)
+    uint32_t tile_bytes_cap;      // bytes of the staging buffer, multiple of 1024
 };
 
 // stats slots, must match include/pssbam_hip.h
@@ -218,28 +217,30 @@ __device__ __forceinline__ uint32_t read_nibble(const Src &src, const RecHdr &h,
 
 // ---- what to do with one record ---------------------------------------------------------
 struct Plan {
-    uint32_t st_mask;        // bit per stats slot this record increments
+    uint32_t st_mask;        // bit per stats slot this record increments (pss bits added by finish)
     bool live;               // record reached process_aln with a known contig
     uint64_t gbase;          // genome offset of the contig's first base
     int64_t s;               // 0-based alignment start
     bool rev;                // FLAG 0x10
+    uint32_t flag;
     // pss
-    bool pss_fwd, pss_rev;   // which table(s) this read is tallied into
+    bool pss_cand;           // passed every pss filter that does not look at the genome
+    bool pss_fwd, pss_rev;   // which table(s) this read is tallied into (set by plan_finish_pss)
     uint32_t L;              // pss effective length: |TLEN| when paired else strlen(SEQ)
     // fragkon
     bool fk5, fk3;           // which k-mer table(s) this read may add to
     uint32_t Lk;             // strlen(SEQ)
 };
 
-// Text-equivalence + contig lookup + both tools' filters.  Genome bytes are read for the
-// -U/-D context test only.
+// Text-equivalence + contig lookup + both tools' filters, everything that can be decided
+// from the record alone.  No genome access.
 template <class Src>
-__device__ Plan make_plan(const TallyParams &P, const Src &src, const RecHdr &h) {
+__device__ Plan plan_head(const TallyParams &P, const Src &src, const RecHdr &h) {
     Plan pl;
     pl.st_mask = 1u << ST_RECORDS;
     pl.live = false;
-    pl.pss_fwd = pl.pss_rev = pl.fk5 = pl.fk3 = false;
-    pl.gbase = 0; pl.s = 0; pl.rev = false; pl.L = 0; pl.Lk = 0;
+    pl.pss_cand = pl.pss_fwd = pl.pss_rev = pl.fk5 = pl.fk3 = false;
+    pl.gbase = 0; pl.s = 0; pl.rev = false; pl.L = 0; pl.Lk = 0; pl.flag = h.flag;
 
     if (P.rg && !has_read_group(src, h, P.rg, P.rg_len)) { pl.st_mask |= 1u << ST_RG_DROPPED; return pl; }
 
@@ -261,7 +262,6 @@ __device__ Plan make_plan(const TallyParams &P, const Src &src, const RecHdr &h)
     const bool paired = (h.flag & FL_PAIRED) != 0;
     const uint32_t op_len = h.cigar0 >> 4;
     const bool single_m = (h.n_cigar == 1) && ((h.cigar0 & 0xFu) == 0u);  // cigar_ok: "<len>M"
-    const uint8_t *G = P.genome + pl.gbase;
 
     if (P.tally_mask & 1u) {
         // process_aln filters, pss-bam.c:401-420
@@ -272,19 +272,9 @@ __device__ Plan make_plan(const TallyParams &P, const Src &src, const RecHdr &h)
         ok = ok && (uint64_t)L >= P.pss_min_len && (uint64_t)L <= P.pss_max_len && (int64_t)L >= (int64_t)P.N;
         ok = ok && single_m && op_len == L;
         ok = ok && !(h.flag & FL_REJECT) && !(P.pss_merged_only && paired);
-        if (ok) {
-            // first context base each side, in read orientation (pss-bam.c:134-142, :461, :472)
-            const uint32_t up = pl.rev ? comp_stored(G[pl.s + L]) : G[pl.s - 1];
-            const uint32_t dn = pl.rev ? comp_stored(G[pl.s - 1]) : G[pl.s + L];
-            const bool up_ok = in_set(P.up_mask, up), dn_ok = in_set(P.down_mask, dn);
-            if (!paired) {
-                pl.pss_fwd = pl.pss_rev = up_ok && dn_ok;                       // :428-447
-            } else if ((h.flag & FL_PROPER) && !(h.flag & FL_MUNMAP)) {         // :450-494
-                if ((h.flag & FL_READ1) && up_ok) pl.pss_fwd = true;
-                else if ((h.flag & FL_READ2) && dn_ok) pl.pss_rev = true;
-            }
-        }
-        pl.st_mask |= (pl.pss_fwd || pl.pss_rev) ? (1u << ST_PSS_OK) : (1u << ST_PSS_FILTERED);
+        // paired reads additionally need proper_pair && !munmap and a mate number (:450-452,:460,:471)
+        if (paired) ok = ok && (h.flag & FL_PROPER) && !(h.flag & FL_MUNMAP) && (h.flag & (FL_READ1 | FL_READ2));
+        pl.pss_cand = ok;
     }
     if (P.tally_mask & 2u) {
         // process_aln filters, fragkon.c:129-146 (+ precondition P4: start >= k/2)
@@ -306,6 +296,40 @@ __device__ Plan make_plan(const TallyParams &P, const Src &src, const RecHdr &h)
         }
         if (!pl.fk5 && !pl.fk3) pl.st_mask |= 1u << ST_KMER_FILTERED;
     }
+    return pl;
+}
+
+// The -U / -D context test and the table choice (pss-bam.c:134-142, :428-494).
+// left1 / right1 = STORED genome bytes at s-1 and s+L (first context base on each side of
+// the alignment, reference orientation).  Adds the pss stats bit.
+__device__ __forceinline__ void plan_finish_pss(const TallyParams &P, Plan &pl, uint32_t left1, uint32_t right1) {
+    if (!(P.tally_mask & 1u)) return;
+    if (pl.live && pl.pss_cand) {
+        // first context base each side, in read orientation (reverse reads: revcomp'ed window)
+        const uint32_t up = pl.rev ? comp_stored(right1) : left1;
+        const uint32_t dn = pl.rev ? comp_stored(left1) : right1;
+        const bool up_ok = in_set(P.up_mask, up), dn_ok = in_set(P.down_mask, dn);
+        if (!(pl.flag & FL_PAIRED)) {
+            pl.pss_fwd = pl.pss_rev = up_ok && dn_ok;                              // :428-447
+        } else {                                                                   // :450-494
+            if ((pl.flag & FL_READ1) && up_ok) pl.pss_fwd = true;
+            else if ((pl.flag & FL_READ2) && dn_ok) pl.pss_rev = true;
+        }
+    }
+    if (pl.live) pl.st_mask |= (pl.pss_fwd || pl.pss_rev) ? (1u << ST_PSS_OK) : (1u << ST_PSS_FILTERED);
+}
+
+// both steps with the two context bytes fetched from global memory (lane-per-read kernels)
+template <class Src>
+__device__ Plan make_plan(const TallyParams &P, const Src &src, const RecHdr &h) {
+    Plan pl = plan_head(P, src, h);
+    uint32_t l1 = 0, r1 = 0;
+    if (pl.pss_cand) {
+        const uint8_t *G = P.genome + pl.gbase;
+        l1 = G[pl.s - 1];
+        r1 = G[pl.s + pl.L];
+    }
+    plan_finish_pss(P, pl, l1, r1);
     return pl;
 }
 

@@ -36,7 +36,7 @@ namespace pssbam {
 constexpr int TILED_THREADS = 256;
 constexpr int TILED_WAVES = TILED_THREADS / 64;
 constexpr int TILED_MAX_N = 30;        // N+2 positions per end must fit 32 lanes
-constexpr int WIN_DWORDS = 9;          // (N+2) + 3 alignment bytes <= 36
+constexpr int WIN_DWORDS = 9;          // 32 window bytes + 3 alignment bytes <= 36
 constexpr int KMER_LDS_MAX_K = 5;      // 2 * 4^5 * 4 B = 8 KiB of LDS
 constexpr uint32_t STAGE_SLACK = 64;   // readable bytes behind a staging buffer
 constexpr uint32_t PAIR_LUT_BYTES = 2 * 17 * 8;
@@ -178,14 +178,15 @@ __global__ void __launch_bounds__(256) tally_simple(const TallyParams P) {
 // tally_tiled
 // ---------------------------------------------------------------------------------------
 // dynamic LDS carve-up (all 16-byte aligned):
-//   stage[n_bufs] : tile_bytes_cap + STAGE_SLACK each   raw BAM bytes of a tile
-//   sheet         : T * 64                               code sheet [read][end*32 + position]
-//   table         : 32 * 32 * 4                          [(cell<<1)|table][row] u32
-//   lut           : PAIR_LUT_BYTES (padded to 16)        (strand, nibble row, ref code) -> code
-//   kmer          : 2 * 4^K * 4   (only when K <= KMER_LDS_MAX_K and the k-mer tally is on)
+//   stage  : tile_bytes_cap + STAGE_SLACK      raw BAM bytes of the current tile
+//   sheet  : T * 64                            code sheet [read][end*32 + position]
+//   table  : 32 * 32 * 4                       [(cell<<1)|table][row] u32
+//   lut    : PAIR_LUT_BYTES (padded to 16)     (strand, nibble row, ref code) -> code
+//   toffs  : (T + 8) * 4                       the tile's record offsets (+ next tile's geometry)
+//   kmer   : 2 * 4^K * 4   (only when K <= KMER_LDS_MAX_K and the k-mer tally is on)
 __host__ __device__ inline uint32_t tiled_stage_stride(uint32_t cap) { return (cap + STAGE_SLACK + 15u) & ~15u; }
-__host__ __device__ inline uint32_t tiled_lds_bytes(uint32_t T, uint32_t cap, uint32_t n_bufs, bool kmer_lds, int K) {
-    uint32_t b = n_bufs * tiled_stage_stride(cap) + T * 64u + 32u * 32u * 4u + ((PAIR_LUT_BYTES + 15u) & ~15u);
+__host__ __device__ inline uint32_t tiled_lds_bytes(uint32_t T, uint32_t cap, bool kmer_lds, int K) {
+    uint32_t b = tiled_stage_stride(cap) + T * 64u + 32u * 32u * 4u + ((PAIR_LUT_BYTES + 15u) & ~15u) + (T + 8u) * 4u;
     if (kmer_lds) b += 2u * (1u << (2 * K)) * 4u;
     return b;
 }
@@ -204,6 +205,10 @@ __device__ __forceinline__ void stage_tile_dma(const uint8_t *recs, uint32_t bas
     }
 }
 
+// Reference windows, one per alignment end, each with STATIC byte positions:
+//   left  end (e = 0): 32 bytes from s-2      byte w <-> row w          (0,1 context; 2+i = position i)
+//   right end (e = 1): 32 bytes up to s+L+1   byte w <-> row 31-w       (31 -> row 0, 30 -> row 1, 29-i -> 2+i)
+// Read bases: left row 2+i <-> base i ; right row 2+i <-> base L-1-i, i.e. window byte w <-> base (L-30)+w.
 template <bool DO_PSS, bool DO_KMER, bool LDS_KMER>
 __global__ void __launch_bounds__(TILED_THREADS) tally_tiled(const TallyParams P) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
@@ -211,19 +216,18 @@ __global__ void __launch_bounds__(TILED_THREADS) tally_tiled(const TallyParams P
 
     const uint32_t T = P.reads_per_tile;
     const uint32_t cap = P.tile_bytes_cap;
-    const uint32_t n_bufs = P.n_stage_bufs;
-    const uint32_t stage_stride = tiled_stage_stride(cap);
-    uint8_t *stage0 = lds_raw;
-    uint8_t *sheet = lds_raw + n_bufs * stage_stride;
+    uint8_t *stage = lds_raw;
+    uint8_t *sheet = lds_raw + tiled_stage_stride(cap);
     uint32_t *table = (uint32_t *)(sheet + T * 64u);
     uint8_t *lut = (uint8_t *)(table + 32u * 32u);
-    uint32_t *lds_kmer = (uint32_t *)(lut + ((PAIR_LUT_BYTES + 15u) & ~15u));
+    uint32_t *toffs = (uint32_t *)(lut + ((PAIR_LUT_BYTES + 15u) & ~15u));
+    uint32_t *tgeo = toffs + T + 4u;   // [0] = offs[first read of next tile], [1] = offs[one past its last]
+    uint32_t *lds_kmer = toffs + T + 8u;
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u, wave = tid >> 6;
     const int N = P.N;
-    const uint32_t n_pos = (uint32_t)N + 2u;                 // positions per end: 2 context + N
-    const uint32_t win_dw = ((uint32_t)N + 5u + 3u) >> 2;    // dwords covering n_pos bytes at any shift
+    const uint32_t n_pos = (uint32_t)N + 2u;  // rows per table: 2 context + N positions
 
     // ---- one-time set-up: zero the tables, build the pair LUT ---------------------------------
     for (uint32_t i = tid; i < 32u * 32u; i += TILED_THREADS) table[i] = 0u;
@@ -248,116 +252,140 @@ __global__ void __launch_bounds__(TILED_THREADS) tally_tiled(const TallyParams P
     for (int i = 0; i < ST_USED; i++) my_stats[i] = 0u;
 
     const uint32_t n_tiles = (P.n_recs + T - 1u) / T;
-    uint32_t tile = blockIdx.x;
-    // geometry of a tile's byte range
-    auto tile_range = [&](uint32_t t, uint32_t &base16, uint32_t &staged) {
-        const uint32_t r0 = t * T, r1 = min(r0 + T, P.n_recs);
-        const uint32_t o_first = P.offs[r0], o_last = P.offs[r1];
+    const uint32_t tstride = gridDim.x;
+    auto geom = [&](uint32_t o_first, uint32_t o_last, uint32_t &base16, uint32_t &staged) {
         base16 = o_first & ~15u;
         staged = min((o_last - base16 + 15u) & ~15u, cap);
     };
-    uint32_t base16 = 0, staged = 0;
+    // software pipeline over this workgroup's tiles k0, k0+stride, ...:
+    //   cur_*  geometry of the tile being processed (its bytes are / will be in `stage`)
+    //   off_a/b  this thread's slice of the tile's offsets, loaded one tile ahead (VGPRs)
+    //   geo    offs[] at the ends of the tile AFTER the next one, loaded two tiles ahead by lanes 0/1
+    uint32_t tile = blockIdx.x;
+    uint32_t cur_base16 = 0, cur_staged = 0;
+    uint32_t off_a = 0, off_b = 0, geo = 0;
+    auto load_offsets = [&](uint32_t t) {
+        const uint32_t r0 = t * T;
+        if (tid <= T && r0 + tid <= P.n_recs) off_a = P.offs[r0 + tid];
+        if (tid + TILED_THREADS <= T && r0 + tid + TILED_THREADS <= P.n_recs) off_b = P.offs[r0 + tid + TILED_THREADS];
+    };
+    auto load_geo = [&](uint32_t t) {
+        if (tid < 2u) geo = P.offs[tid == 0u ? t * T : min(t * T + T, P.n_recs)];
+    };
     if (tile < n_tiles) {
-        tile_range(tile, base16, staged);
-        stage_tile_dma(P.recs, base16, staged, stage0, wave, lane);
+        geom(P.offs[tile * T], P.offs[min(tile * T + T, P.n_recs)], cur_base16, cur_staged);
+        load_offsets(tile);
+        stage_tile_dma(P.recs, cur_base16, cur_staged, stage, wave, lane);
+        if (tile + tstride < n_tiles) load_geo(tile + tstride);
     }
 
-    for (uint32_t it = 0; tile < n_tiles; tile += gridDim.x, it++) {
-        const uint32_t cur = (n_bufs == 2u) ? (it & 1u) : 0u;
-        uint8_t *stage = stage0 + cur * stage_stride;
+    for (; tile < n_tiles; tile += tstride) {
         const uint32_t r0 = tile * T;
         const uint32_t count = min(T, P.n_recs - r0);
+        const uint32_t next = tile + tstride;
 
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces have landed
-        __syncthreads();                                    // ... everyone's; previous COLUMNS pass is over
-
-        const uint32_t next = tile + gridDim.x;
-        uint32_t nbase16 = 0, nstaged = 0;
-        if (n_bufs == 2u && next < n_tiles) {               // prefetch the next tile behind the compute
-            tile_range(next, nbase16, nstaged);
-            stage_tile_dma(P.recs, nbase16, nstaged, stage0 + (cur ^ 1u) * stage_stride, wave, lane);
-        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // DMA pieces + offset loads of this wave are in
+        if (tid <= T) toffs[tid] = off_a;
+        if (tid + TILED_THREADS <= T) toffs[tid + TILED_THREADS] = off_b;
+        if (tid < 2u) tgeo[tid] = geo;
+        __syncthreads();  // everyone's DMA landed; previous COLUMNS pass is over
+        uint32_t nxt_base16 = 0, nxt_staged = 0;
+        if (next < n_tiles) geom(tgeo[0], tgeo[1], nxt_base16, nxt_staged);
 
         // ---- CODES: lane pair per read ------------------------------------------------------
         for (uint32_t p = tid; p < 2u * T; p += TILED_THREADS) {
             const uint32_t j = p >> 1, e = p & 1u;  // e = 0: left alignment end, 1: right end
+            const bool in_tile = j < count;
+            uint32_t o0 = 0, o1 = 0;
+            if (in_tile) { o0 = toffs[j]; o1 = toffs[j + 1]; }
+            const bool in_stage = in_tile && (o1 - cur_base16 <= cur_staged);
+            LdsBytes src{stage + (o0 - cur_base16)};
+            RecHdr h;
+            Plan pl;
+            pl.st_mask = 0u; pl.live = false; pl.pss_cand = pl.pss_fwd = pl.pss_rev = pl.fk5 = pl.fk3 = false;
+            pl.rev = false; pl.L = 0; pl.Lk = 0; pl.s = 0; pl.gbase = 0; pl.flag = 0;
+            h.l_seq = 0; h.seq_off = 0;
+            if (in_stage) {
+                h = decode_hdr(src, o1 - o0);
+                pl = plan_head(P, src, h);
+            }
+            // this end's reference window, issued for every candidate before the -U/-D test so the
+            // test costs no extra memory round trip
+            const bool cand = DO_PSS && pl.pss_cand;
+            uint32_t gw[WIN_DWORDS];
+#pragma unroll
+            for (int k = 0; k < WIN_DWORDS; k++) gw[k] = 0u;
+            if (cand) {
+                const uint64_t ga = pl.gbase + (uint64_t)pl.s + (e ? (uint64_t)pl.L - 30ull : (uint64_t)-2ll);
+                const uint32_t *pg = (const uint32_t *)(P.genome + (ga & ~3ull));
+#pragma unroll
+                for (int k = 0; k < WIN_DWORDS; k++) gw[k] = pg[k];
+                const uint32_t gsh = (uint32_t)(ga & 3ull);
+#pragma unroll
+                for (int k = 0; k < WIN_DWORDS - 1; k++) gw[k] = __builtin_amdgcn_alignbyte(gw[k + 1], gw[k], gsh);
+            }
+            // first context base next to the alignment: left window byte 1 (s-1), right window byte 30 (s+L)
+            const uint32_t own1 = e ? (gw[7] >> 16) & 0xFFu : (gw[0] >> 8) & 0xFFu;
+            const uint32_t other1 = (uint32_t)__shfl_xor((int)own1, 1);
+            if (DO_PSS && in_stage) plan_finish_pss(P, pl, e ? other1 : own1, e ? own1 : other1);
+            uint32_t m = pl.st_mask;
+
             uint32_t code_w[8];
 #pragma unroll
             for (int k = 0; k < 8; k++) code_w[k] = 0xFFFFFFFFu;
-            uint32_t m = 0u;
-            bool kmer_try = false, kmer_ok = true;
-            if (j < count) {
-                const uint32_t r = r0 + j;
-                const uint32_t o0 = P.offs[r], o1 = P.offs[r + 1];
-                if (o1 - base16 <= staged) {
-                    LdsBytes src{stage + (o0 - base16)};
-                    const RecHdr h = decode_hdr(src, o1 - o0);
-                    const Plan pl = make_plan(P, src, h);
-                    m = pl.st_mask;
-                    // this lane's end feeds: left -> fwd table on forward reads, rev table on reverse reads
-                    const uint32_t tsel = e ^ (pl.rev ? 1u : 0u);
-                    if (DO_PSS && (tsel ? pl.pss_rev : pl.pss_fwd)) {
-                        // reference window of this end: left = s-2 .. s+N-1, right = s+L-N .. s+L+1
-                        const uint64_t ga = pl.gbase + (uint64_t)pl.s + (e ? (uint64_t)pl.L - (uint32_t)N : (uint64_t)-2ll);
-                        const uint32_t *pg = (const uint32_t *)(P.genome + (ga & ~3ull));
-                        uint32_t gw[WIN_DWORDS];
+            // this lane's end feeds: left -> fwd table on forward reads, rev table on reverse reads
+            const uint32_t tsel = e ^ (pl.rev ? 1u : 0u);
+            if (cand && (tsel ? pl.pss_rev : pl.pss_fwd)) {
+                // read bases of this end as a nibble stream: stream nibble q <-> read base n0 + q
+                const int32_t n0 = e ? (int32_t)pl.L - 30 : 0;
+                const uint32_t sb = (uint32_t)((int32_t)h.seq_off + (n0 >> 1));  // arithmetic shift = floor
+                uint32_t sw[5];
 #pragma unroll
-                        for (int k = 0; k < WIN_DWORDS; k++) gw[k] = (uint32_t)k < win_dw ? pg[k] : 0u;
-                        const uint32_t gsh = (uint32_t)(ga & 3ull);
+                for (int k = 0; k < 5; k++) sw[k] = src.u32(sb + 4u * k);
 #pragma unroll
-                        for (int k = 0; k < WIN_DWORDS - 1; k++) gw[k] = __builtin_amdgcn_alignbyte(gw[k + 1], gw[k], gsh);
-                        // read bases of this end as a nibble stream: stream nibble q <-> read base n0 + q,
-                        // n0 = 0 (left) or L-N (right); position b uses q = b-2 (left, b >= 2) or b (right, b < N)
-                        const uint32_t n0 = e ? pl.L - (uint32_t)N : 0u;
-                        const uint32_t sb = h.seq_off + (n0 >> 1);
-                        uint32_t sw[5];
+                for (int k = 0; k < 5; k++)  // high nibble first -> nibble q at bits 4q
+                    sw[k] = ((sw[k] & 0x0F0F0F0Fu) << 4) | ((sw[k] >> 4) & 0x0F0F0F0Fu);
+                if (n0 & 1) {
 #pragma unroll
-                        for (int k = 0; k < 5; k++) sw[k] = src.u32(sb + 4u * k);
-#pragma unroll
-                        for (int k = 0; k < 5; k++)  // high nibble first -> nibble q at bits 4q
-                            sw[k] = ((sw[k] & 0x0F0F0F0Fu) << 4) | ((sw[k] >> 4) & 0x0F0F0F0Fu);
-                        if (n0 & 1u) {
-#pragma unroll
-                            for (int k = 0; k < 4; k++) sw[k] = (sw[k] >> 4) | (sw[k + 1] << 28);
-                        }
-                        // bases at or beyond l_seq do not exist (precondition P3): blank them
-                        const uint32_t have = h.l_seq > n0 ? min(h.l_seq - n0, 32u) : 0u;
-#pragma unroll
-                        for (int k = 0; k < 4; k++) {
-                            const uint32_t lo = 8u * k;
-                            const uint32_t keep = have >= lo + 8u ? 0xFFFFFFFFu
-                                                 : have > lo ? ((1u << (4u * (have - lo))) - 1u) : 0u;
-                            sw[k] &= keep;
-                        }
-                        const uint8_t *lut_s = lut + (pl.rev ? 136u : 0u);
-#pragma unroll
-                        for (int b = 0; b < 32; b++) {
-                            if ((uint32_t)b < n_pos) {
-                                const uint32_t g = min((gw[b >> 2] >> (8 * (b & 3))) & 0xFFu, 4u);
-                                // context positions: left b < 2, right b >= N
-                                const bool ctx = e ? ((uint32_t)b >= (uint32_t)N) : (b < 2);
-                                const int q = e ? b : b - 2;
-                                const uint32_t nib = (q >= 0 && q < 32) ? (sw[(q >> 3) & 3] >> (4 * (q & 7))) & 0xFu : 0u;
-                                const uint32_t v = lut_s[(ctx ? 16u : nib) * 8u + g];
-                                const uint32_t cb = v == 0xFFu ? 0xFFu : (v | tsel);
-                                code_w[b >> 2] = (code_w[b >> 2] & ~(0xFFu << (8 * (b & 3)))) | (cb << (8 * (b & 3)));
-                            }
-                        }
-                    }
-                    if (DO_KMER && (e ? pl.fk3 : pl.fk5)) {
-                        kmer_try = true;
-                        kmer_ok = tally_one_kmer<LDS_KMER>(P, pl, e, lds_kmer);
-                    }
-                } else if (e == 0u) {
-                    // record does not fit the staging window (huge record): whole thing from global,
-                    // by the first lane of the pair
-                    GlobalBytes src{P.recs + o0};
-                    const RecHdr h = decode_hdr(src, o1 - o0);
-                    const Plan pl = make_plan(P, src, h);
-                    m = pl.st_mask;
-                    if (DO_PSS && (pl.pss_fwd || pl.pss_rev)) tally_pss_record(P, LdsTableColumnMajor{table}, src, h, pl);
-                    if (DO_KMER && (pl.fk5 || pl.fk3)) m |= tally_kmer_record<LDS_KMER>(P, pl, lds_kmer);
+                    for (int k = 0; k < 4; k++) sw[k] = (sw[k] >> 4) | (sw[k + 1] << 28);
                 }
+                // bases at or beyond l_seq do not exist (precondition P3): blank them
+                const int32_t have_s = (int32_t)h.l_seq - n0;
+                const uint32_t have = have_s <= 0 ? 0u : have_s >= 32 ? 32u : (uint32_t)have_s;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t lo = 8u * k;
+                    const uint32_t keep = have >= lo + 8u ? 0xFFFFFFFFu : have > lo ? ((1u << (4u * (have - lo))) - 1u) : 0u;
+                    sw[k] &= keep;
+                }
+                const uint8_t *lut_s = lut + (pl.rev ? 136u : 0u);
+#pragma unroll
+                for (int b = 0; b < 32; b++) {
+                    const uint32_t row = e ? 31u - (uint32_t)b : (uint32_t)b;
+                    if (row < n_pos) {
+                        const uint32_t g = min((gw[b >> 2] >> (8 * (b & 3))) & 0xFFu, 4u);
+                        const int q = e ? b : b - 2;  // stream nibble of this window byte
+                        const uint32_t nib = q >= 0 ? (sw[(q >> 3) & 3] >> (4 * (q & 7))) & 0xFu : 0u;
+                        const uint32_t v = lut_s[(row < 2u ? 16u : nib) * 8u + g];
+                        const uint32_t cb = v == 0xFFu ? 0xFFu : (v | tsel);
+                        code_w[b >> 2] = (code_w[b >> 2] & ~(0xFFu << (8 * (b & 3)))) | (cb << (8 * (b & 3)));
+                    }
+                }
+            }
+            bool kmer_try = false, kmer_ok = true;
+            if (DO_KMER && (e ? pl.fk3 : pl.fk5)) {
+                kmer_try = true;
+                kmer_ok = tally_one_kmer<LDS_KMER>(P, pl, e, lds_kmer);
+            }
+            if (in_tile && !in_stage && e == 0u) {
+                // record does not fit the staging window (huge record): whole thing from global,
+                // by the first lane of the pair
+                GlobalBytes gsrc{P.recs + o0};
+                const RecHdr gh = decode_hdr(gsrc, o1 - o0);
+                const Plan gpl = make_plan(P, gsrc, gh);
+                m = gpl.st_mask;
+                if (DO_PSS && (gpl.pss_fwd || gpl.pss_rev)) tally_pss_record(P, LdsTableColumnMajor{table}, gsrc, gh, gpl);
+                if (DO_KMER && (gpl.fk5 || gpl.fk3)) m |= tally_kmer_record<LDS_KMER>(P, gpl, lds_kmer);
             }
             // code sheet row of read j: bytes [e*32, e*32+32)
             uint4 *dst = (uint4 *)(sheet + j * 64u + e * 32u);
@@ -376,20 +404,24 @@ __global__ void __launch_bounds__(TILED_THREADS) tally_tiled(const TallyParams P
             }
         }
         __syncthreads();
-        if (n_bufs == 1u && next < n_tiles) {
-            // single staging buffer: every wave is past CODES (the only reader of `stage`), so the
-            // next tile's DMA can already run behind the COLUMNS pass
-            tile_range(next, base16, staged);
-            stage_tile_dma(P.recs, base16, staged, stage0, wave, lane);
+
+        // every wave is past CODES (the only reader of `stage` and `toffs`): start the next tile's
+        // DMA and offset loads now, they land behind the COLUMNS pass
+        if (next < n_tiles) {
+            load_offsets(next);
+            stage_tile_dma(P.recs, nxt_base16, nxt_staged, stage, wave, lane);
+            if (next + tstride < n_tiles) load_geo(next + tstride);
+            cur_base16 = nxt_base16;
+            cur_staged = nxt_staged;
         }
 
-        // ---- COLUMNS: wave-per-read, lane = (end, position) --------------------------------------
+        // ---- COLUMNS: wave-per-read, lane = (end, window byte) -----------------------------------
         if (DO_PSS) {
             const uint32_t e = lane >> 5, b = lane & 31u;
-            const uint32_t row = e ? (uint32_t)N + 1u - b : b;   // position -> table row (0,1 context; 2+i)
+            const uint32_t row = e ? 31u - b : b;
             const uint32_t per_wave = (count + TILED_WAVES - 1u) / TILED_WAVES;
             const uint32_t j0 = wave * per_wave, j1 = min(count, j0 + per_wave);
-            if (b < n_pos) {
+            if (row < n_pos) {
                 uint32_t j = j0;
                 for (; j + 8u <= j1; j += 8u) {
                     uint32_t c[8];
@@ -405,7 +437,6 @@ __global__ void __launch_bounds__(TILED_THREADS) tally_tiled(const TallyParams P
                 }
             }
         }
-        if (n_bufs == 2u) { base16 = nbase16; staged = nstaged; }
     }
 
 #pragma unroll
