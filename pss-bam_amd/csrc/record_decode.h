@@ -75,14 +75,17 @@ struct GlobalBytes {
     }
 };
 
-// LDS window: dword-aligned reads + v_alignbyte; the window carries >= 8 bytes of slack
-// behind its last byte so the second dword of an unaligned read is always in bounds.
+// LDS window: dword-aligned reads + v_alignbyte.  Addressed as (16-byte aligned LDS base,
+// byte offset) so the alignment comes from the integer offset and the pointer keeps its
+// address space (ds_read, not flat).  The window carries >= 8 bytes of slack behind its last
+// byte so the second dword of an unaligned read is always in bounds.
 struct LdsBytes {
-    const uint8_t *p;  // points into __shared__ storage
-    __device__ __forceinline__ uint32_t u8(uint32_t o) const { return p[o]; }
+    const uint8_t *base;  // 16-byte aligned __shared__ storage
+    uint32_t off;         // byte offset of the record inside it
+    __device__ __forceinline__ uint32_t u8(uint32_t o) const { return base[off + o]; }
     __device__ __forceinline__ uint32_t u32(uint32_t o) const {
-        const uint32_t a = (uint32_t)(uintptr_t)(p + o);
-        const uint32_t *q = (const uint32_t *)(p + o - (a & 3u));
+        const uint32_t a = off + o;
+        const uint32_t *q = (const uint32_t *)(base + (a & ~3u));
         return __builtin_amdgcn_alignbyte(q[1], q[0], a & 3u);
     }
     __device__ __forceinline__ uint32_t u16(uint32_t o) const { return u32(o) & 0xFFFFu; }
@@ -133,6 +136,41 @@ __device__ __forceinline__ RecHdr decode_hdr(const Src &src, uint32_t rec_len) {
     h.qual_off = (uint32_t)qual_off;
     h.aux_off = (uint32_t)aux_off;
     h.cigar0 = h.n_cigar ? src.u32((uint32_t)cig_off) : 0u;
+    return h;
+}
+
+// Same for a record staged in LDS: the 36 fixed bytes arrive as ten aligned dwords in one batch
+// (one wait) and are funnel-shifted into place, instead of seven unaligned two-read fetches.
+__device__ __forceinline__ RecHdr decode_hdr_lds(const LdsBytes &src, uint32_t rec_len) {
+    const uint32_t sh = src.off & 3u;
+    const uint32_t *q = (const uint32_t *)(src.base + (src.off & ~3u));
+    uint32_t r[10], w[9];
+#pragma unroll
+    for (int k = 0; k < 10; k++) r[k] = q[k];
+#pragma unroll
+    for (int k = 0; k < 9; k++) w[k] = __builtin_amdgcn_alignbyte(r[k + 1], r[k], sh);
+    RecHdr h;
+    h.rec_len = rec_len;
+    h.ref_id = (int32_t)w[1];
+    h.pos = (int32_t)w[2];
+    h.mapq = (w[3] >> 8) & 0xFFu;
+    h.n_cigar = w[4] & 0xFFFFu;
+    h.flag = w[4] >> 16;
+    h.l_seq = w[5];
+    h.tlen = (int32_t)w[8];
+    const uint64_t cig_off = 36ull + (w[3] & 0xFFu);
+    const uint64_t seq_off = cig_off + 4ull * h.n_cigar;
+    const uint64_t qual_off = seq_off + ((uint64_t(h.l_seq) + 1) >> 1);
+    const uint64_t aux_off = qual_off + h.l_seq;
+    h.well_formed = rec_len >= 36u && aux_off <= rec_len;
+    // a malformed record decodes as "unmapped, no bases"; offsets clamped so nothing is read
+    // outside the record
+    h.seq_off = h.well_formed ? (uint32_t)seq_off : rec_len;
+    h.qual_off = h.well_formed ? (uint32_t)qual_off : rec_len;
+    h.aux_off = h.well_formed ? (uint32_t)aux_off : rec_len;
+    const uint32_t c0 = src.u32(h.well_formed ? (uint32_t)cig_off : 0u);
+    h.cigar0 = (h.well_formed && h.n_cigar) ? c0 : 0u;
+    if (!h.well_formed) { h.n_cigar = 0; h.l_seq = 0; h.flag |= FL_UNMAP; h.ref_id = -1; }
     return h;
 }
 
@@ -233,82 +271,98 @@ struct Plan {
 };
 
 // Text-equivalence + contig lookup + both tools' filters, everything that can be decided
-// from the record alone.  No genome access.
+// from the record alone.  No genome access.  Written as straight-line predicated code (the
+// lanes of a wave hold different records; early returns would only serialise them).
 template <class Src>
-__device__ Plan plan_head(const TallyParams &P, const Src &src, const RecHdr &h) {
+__device__ __forceinline__ Plan plan_head(const TallyParams &P, const Src &src, const RecHdr &h) {
     Plan pl;
-    pl.st_mask = 1u << ST_RECORDS;
-    pl.live = false;
-    pl.pss_cand = pl.pss_fwd = pl.pss_rev = pl.fk5 = pl.fk3 = false;
-    pl.gbase = 0; pl.s = 0; pl.rev = false; pl.L = 0; pl.Lk = 0; pl.flag = h.flag;
+    pl.pss_fwd = pl.pss_rev = false;
+    pl.flag = h.flag;
 
-    if (P.rg && !has_read_group(src, h, P.rg, P.rg_len)) { pl.st_mask |= 1u << ST_RG_DROPPED; return pl; }
+    bool rg_drop = false;
+    if (P.rg) rg_drop = !has_read_group(src, h, P.rg, P.rg_len);  // uniform branch (kernel argument)
 
     // line2saml: strlen(SEQ) vs strlen(QUAL)  (sam-parse.c:50)
     const uint32_t l_text = h.l_seq ? h.l_seq : 1u;
-    const bool qual_star = (h.l_seq == 0) || (src.u8(h.qual_off) == 0xFFu);
-    if (!h.well_formed || (qual_star && l_text != 1u)) { pl.st_mask |= 1u << ST_PARSE_SKIP; return pl; }
+    const uint32_t q0 = (h.well_formed && h.l_seq) ? src.u8(h.qual_off) : 0xFFu;
+    const bool qual_star = (h.l_seq == 0) || (q0 == 0xFFu);
+    const bool parse_skip = !rg_drop && (!h.well_formed || (qual_star && l_text != 1u));
 
-    // find_seq(genome, RNAME)  (pss-bam.c:393-396, fragkon.c:124-127)
-    int32_t contig = -1;
-    if (h.ref_id >= 0 && h.ref_id < P.n_ref) contig = P.ref_map[h.ref_id];
-    else if (h.ref_id == -1) contig = P.star_contig;
-    if (contig < 0) { pl.st_mask |= 1u << ST_NO_CONTIG; return pl; }
-    const uint64_t glen = P.contig_len[contig];
-    pl.gbase = P.contig_start[contig];
-    pl.live = true;
+    // find_seq(genome, RNAME)  (pss-bam.c:393-396, fragkon.c:124-127); tables have one spare entry
+    const bool rid_ok = h.ref_id >= 0 && h.ref_id < P.n_ref;
+    const int32_t mapped = P.ref_map[rid_ok ? h.ref_id : 0];
+    const int32_t contig = rid_ok ? mapped : (h.ref_id == -1 ? P.star_contig : -1);
+    const bool parsed = !rg_drop && !parse_skip;
+    const bool live = parsed && contig >= 0;
+    const uint64_t glen = P.contig_len[contig >= 0 ? contig : 0];
+    pl.gbase = P.contig_start[contig >= 0 ? contig : 0];
+    pl.live = live;
     pl.s = h.pos;  // POS-1
     pl.rev = (h.flag & FL_REVERSE) != 0;
+    pl.st_mask = (1u << ST_RECORDS) | (rg_drop ? 1u << ST_RG_DROPPED : 0u) | (parse_skip ? 1u << ST_PARSE_SKIP : 0u) |
+                 ((parsed && contig < 0) ? 1u << ST_NO_CONTIG : 0u);
     const bool paired = (h.flag & FL_PAIRED) != 0;
     const uint32_t op_len = h.cigar0 >> 4;
     const bool single_m = (h.n_cigar == 1) && ((h.cigar0 & 0xFu) == 0u);  // cigar_ok: "<len>M"
+    const bool flags_ok = !(h.flag & FL_REJECT);
+    const bool pair_ok = (h.flag & FL_PROPER) && !(h.flag & FL_MUNMAP);
 
-    if (P.tally_mask & 1u) {
-        // process_aln filters, pss-bam.c:401-420
+    {   // process_aln filters, pss-bam.c:401-420
         const uint32_t L = paired ? (uint32_t)(h.tlen < 0 ? -(int64_t)h.tlen : (int64_t)h.tlen) : l_text;
         pl.L = L;
-        bool ok = glen > 0 && pl.s >= 2 && (uint64_t)(pl.s + (int64_t)L + 2) <= glen;
+        bool ok = live && (P.tally_mask & 1u) && glen > 0 && pl.s >= 2 && (uint64_t)(pl.s + (int64_t)L + 2) <= glen;
         ok = ok && !(h.mapq < P.pss_min_mq);
         ok = ok && (uint64_t)L >= P.pss_min_len && (uint64_t)L <= P.pss_max_len && (int64_t)L >= (int64_t)P.N;
         ok = ok && single_m && op_len == L;
-        ok = ok && !(h.flag & FL_REJECT) && !(P.pss_merged_only && paired);
+        ok = ok && flags_ok && !(P.pss_merged_only && paired);
         // paired reads additionally need proper_pair && !munmap and a mate number (:450-452,:460,:471)
-        if (paired) ok = ok && (h.flag & FL_PROPER) && !(h.flag & FL_MUNMAP) && (h.flag & (FL_READ1 | FL_READ2));
+        ok = ok && (!paired || (pair_ok && (h.flag & (FL_READ1 | FL_READ2))));
         pl.pss_cand = ok;
     }
-    if (P.tally_mask & 2u) {
-        // process_aln filters, fragkon.c:129-146 (+ precondition P4: start >= k/2)
+    {   // process_aln filters, fragkon.c:129-146 (+ precondition P4: start >= k/2)
         const uint32_t L = l_text;
         const uint32_t okk = (uint32_t)P.K / 2u;
         pl.Lk = L;
-        bool ok = glen > 0 && pl.s >= (int64_t)okk && (uint64_t)(pl.s + (int64_t)L + okk) <= glen;
+        bool ok = live && (P.tally_mask & 2u) && glen > 0 && pl.s >= (int64_t)okk &&
+                  (uint64_t)(pl.s + (int64_t)L + okk) <= glen;
         ok = ok && h.mapq >= P.fk_min_mq;
         ok = ok && (uint64_t)L >= P.fk_min_len && (uint64_t)L <= P.fk_max_len;
         ok = ok && single_m && op_len == L;
-        ok = ok && !(h.flag & FL_REJECT);
-        if (ok) {
-            if (!paired) {
-                pl.fk5 = pl.fk3 = true;                                          // :149-183
-            } else if (!P.fk_merged_only && (h.flag & FL_PROPER) && !(h.flag & FL_MUNMAP)) {  // :187-213
-                if (h.flag & FL_READ1) pl.fk5 = true;
-                else if (h.flag & FL_READ2) pl.fk3 = true;
-            }
-        }
-        if (!pl.fk5 && !pl.fk3) pl.st_mask |= 1u << ST_KMER_FILTERED;
+        ok = ok && flags_ok;
+        // unpaired: both ends (:149-183, no -m test); paired: needs !MERGED_ONLY && proper && !munmap,
+        // read1 -> 5' only, else read2 -> 3' only (:187-213)
+        const bool pok = ok && paired && !P.fk_merged_only && pair_ok;
+        pl.fk5 = (ok && !paired) || (pok && (h.flag & FL_READ1));
+        pl.fk3 = (ok && !paired) || (pok && !(h.flag & FL_READ1) && (h.flag & FL_READ2));
+        if (live && (P.tally_mask & 2u) && !pl.fk5 && !pl.fk3) pl.st_mask |= 1u << ST_KMER_FILTERED;
     }
     return pl;
 }
 
+// -U / -D membership providers over STORED genome bytes
+struct CtxMasks {  // straight from the kernel arguments
+    const TallyParams &P;
+    __device__ __forceinline__ bool up(uint32_t b) const { return in_set(P.up_mask, b); }
+    __device__ __forceinline__ bool down(uint32_t b) const { return in_set(P.down_mask, b); }
+};
+struct CtxLds {  // 256-byte LDS table: bit 0 = in UP_CTX, bit 1 = in DOWN_CTX
+    const uint8_t *f;
+    __device__ __forceinline__ bool up(uint32_t b) const { return f[b & 0xFFu] & 1u; }
+    __device__ __forceinline__ bool down(uint32_t b) const { return (f[b & 0xFFu] >> 1) & 1u; }
+};
+
 // The -U / -D context test and the table choice (pss-bam.c:134-142, :428-494).
 // left1 / right1 = STORED genome bytes at s-1 and s+L (first context base on each side of
 // the alignment, reference orientation).  Adds the pss stats bit.
-__device__ __forceinline__ void plan_finish_pss(const TallyParams &P, Plan &pl, uint32_t left1, uint32_t right1) {
+template <class Ctx>
+__device__ __forceinline__ void plan_finish_pss(const TallyParams &P, const Ctx &ctx, Plan &pl, uint32_t left1,
+                                                uint32_t right1) {
     if (!(P.tally_mask & 1u)) return;
     if (pl.live && pl.pss_cand) {
         // first context base each side, in read orientation (reverse reads: revcomp'ed window)
         const uint32_t up = pl.rev ? comp_stored(right1) : left1;
         const uint32_t dn = pl.rev ? comp_stored(left1) : right1;
-        const bool up_ok = in_set(P.up_mask, up), dn_ok = in_set(P.down_mask, dn);
+        const bool up_ok = ctx.up(up), dn_ok = ctx.down(dn);
         if (!(pl.flag & FL_PAIRED)) {
             pl.pss_fwd = pl.pss_rev = up_ok && dn_ok;                              // :428-447
         } else {                                                                   // :450-494
@@ -329,7 +383,7 @@ __device__ Plan make_plan(const TallyParams &P, const Src &src, const RecHdr &h)
         l1 = G[pl.s - 1];
         r1 = G[pl.s + pl.L];
     }
-    plan_finish_pss(P, pl, l1, r1);
+    plan_finish_pss(P, CtxMasks{P}, pl, l1, r1);
     return pl;
 }
 

@@ -13,7 +13,7 @@
 //                   2. CODES   a lane pair per read (one lane per alignment end): decode
 //                              + filters from LDS, gather the end's reference window
 //                              (N+2 bytes) from the device genome, turn the N+2 positions
-//                              into one byte each = (cell << 1 | table) or 0xFF, through a
+//                              into one byte each = (cell << 1 | table) or CODE_NONE, through a
 //                              272-byte LDS lookup table indexed by (read nibble,
 //                              reference code, strand), and store the 2 x 32 bytes of the
 //                              read's row of the code sheet.  K-mer windows are tallied
@@ -40,6 +40,8 @@ constexpr int WIN_DWORDS = 9;          // 32 window bytes + 3 alignment bytes <=
 constexpr int KMER_LDS_MAX_K = 5;      // 2 * 4^5 * 4 B = 8 KiB of LDS
 constexpr uint32_t STAGE_SLACK = 64;   // readable bytes behind a staging buffer
 constexpr uint32_t PAIR_LUT_BYTES = 2 * 17 * 8;
+constexpr uint32_t CODE_NONE = 32;     // sheet byte meaning "no count" (33 once the table bit is OR-ed in)
+constexpr uint32_t TABLE_WORDS = 34 * 32;
 
 // ---------------------------------------------------------------------------------------
 // per-read tally, lane-per-read form (tally_simple, and tile-overflow records)
@@ -180,13 +182,15 @@ __global__ void __launch_bounds__(256) tally_simple(const TallyParams P) {
 // dynamic LDS carve-up (all 16-byte aligned):
 //   stage  : tile_bytes_cap + STAGE_SLACK      raw BAM bytes of the current tile
 //   sheet  : T * 64                            code sheet [read][end*32 + position]
-//   table  : 32 * 32 * 4                       [(cell<<1)|table][row] u32
+//   table  : 34 * 32 * 4                       [(cell<<1)|table][row] u32; rows 32,33 = trash bin for
+//                                              "no count" codes, so the column pass needs no branches
 //   lut    : PAIR_LUT_BYTES (padded to 16)     (strand, nibble row, ref code) -> code
+//   ctxf   : 256                               -U / -D membership flags per stored genome byte
 //   toffs  : (T + 8) * 4                       the tile's record offsets (+ next tile's geometry)
 //   kmer   : 2 * 4^K * 4   (only when K <= KMER_LDS_MAX_K and the k-mer tally is on)
 __host__ __device__ inline uint32_t tiled_stage_stride(uint32_t cap) { return (cap + STAGE_SLACK + 15u) & ~15u; }
 __host__ __device__ inline uint32_t tiled_lds_bytes(uint32_t T, uint32_t cap, bool kmer_lds, int K) {
-    uint32_t b = tiled_stage_stride(cap) + T * 64u + 32u * 32u * 4u + ((PAIR_LUT_BYTES + 15u) & ~15u) + (T + 8u) * 4u;
+    uint32_t b = tiled_stage_stride(cap) + T * 64u + TABLE_WORDS * 4u + ((PAIR_LUT_BYTES + 15u) & ~15u) + 256u + (T + 8u) * 4u;
     if (kmer_lds) b += 2u * (1u << (2 * K)) * 4u;
     return b;
 }
@@ -205,6 +209,24 @@ __device__ __forceinline__ void stage_tile_dma(const uint8_t *recs, uint32_t bas
     }
 }
 
+// A record too large for the staging window: decoded and tallied straight from global memory
+// by one lane.  Rare (a record of tens of KB); kept out of line so it costs the hot path
+// nothing.  It reads the kernel arguments through a pointer to the kernarg segment (taken in
+// the kernel): a reference to the kernel's by-value copy would force that whole struct into
+// scratch memory.
+template <bool DO_PSS, bool DO_KMER, bool LDS_KMER>
+__device__ __attribute__((noinline)) uint32_t tally_overflow_record(const TallyParams *kernarg, uint32_t o0,
+                                                                    uint32_t o1, uint32_t *table, uint32_t *lds_kmer) {
+    const TallyParams &P = *kernarg;
+    GlobalBytes gsrc{P.recs + o0};
+    const RecHdr gh = decode_hdr(gsrc, o1 - o0);
+    const Plan gpl = make_plan(P, gsrc, gh);
+    uint32_t m = gpl.st_mask;
+    if (DO_PSS && (gpl.pss_fwd || gpl.pss_rev)) tally_pss_record(P, LdsTableColumnMajor{table}, gsrc, gh, gpl);
+    if (DO_KMER && (gpl.fk5 || gpl.fk3)) m |= tally_kmer_record<LDS_KMER>(P, gpl, lds_kmer);
+    return m;
+}
+
 // Reference windows, one per alignment end, each with STATIC byte positions:
 //   left  end (e = 0): 32 bytes from s-2      byte w <-> row w          (0,1 context; 2+i = position i)
 //   right end (e = 1): 32 bytes up to s+L+1   byte w <-> row 31-w       (31 -> row 0, 30 -> row 1, 29-i -> 2+i)
@@ -214,13 +236,16 @@ __global__ void __launch_bounds__(TILED_THREADS) tally_tiled(const TallyParams P
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     __shared__ uint32_t lds_stats[ST_USED];
 
+    // the kernel's single argument, as it lies in the kernarg segment (for the out-of-line path)
+    const TallyParams *kernarg = (const TallyParams *)__builtin_amdgcn_kernarg_segment_ptr();
     const uint32_t T = P.reads_per_tile;
     const uint32_t cap = P.tile_bytes_cap;
     uint8_t *stage = lds_raw;
     uint8_t *sheet = lds_raw + tiled_stage_stride(cap);
     uint32_t *table = (uint32_t *)(sheet + T * 64u);
-    uint8_t *lut = (uint8_t *)(table + 32u * 32u);
-    uint32_t *toffs = (uint32_t *)(lut + ((PAIR_LUT_BYTES + 15u) & ~15u));
+    uint8_t *lut = (uint8_t *)(table + TABLE_WORDS);
+    uint8_t *ctxf = lut + ((PAIR_LUT_BYTES + 15u) & ~15u);
+    uint32_t *toffs = (uint32_t *)(ctxf + 256u);
     uint32_t *tgeo = toffs + T + 4u;   // [0] = offs[first read of next tile], [1] = offs[one past its last]
     uint32_t *lds_kmer = toffs + T + 8u;
 
@@ -230,7 +255,7 @@ __global__ void __launch_bounds__(TILED_THREADS) tally_tiled(const TallyParams P
     const uint32_t n_pos = (uint32_t)N + 2u;  // rows per table: 2 context + N positions
 
     // ---- one-time set-up: zero the tables, build the pair LUT ---------------------------------
-    for (uint32_t i = tid; i < 32u * 32u; i += TILED_THREADS) table[i] = 0u;
+    for (uint32_t i = tid; i < TABLE_WORDS; i += TILED_THREADS) table[i] = 0u;
     if (LDS_KMER)
         for (uint32_t i = tid; i < 2u * (1u << (2 * P.K)); i += TILED_THREADS) lds_kmer[i] = 0u;
     if (tid < ST_USED) lds_stats[tid] = 0u;
@@ -239,12 +264,30 @@ __global__ void __launch_bounds__(TILED_THREADS) tally_tiled(const TallyParams P
         // (cell of a context base is the diagonal one, pss-bam.c:172-184); g = min(stored, 4)
         const uint32_t strand = i / 136u, row = (i % 136u) >> 3, g = i & 7u;
         const uint32_t rd = row == 16u ? g : nib_code(row);
-        uint32_t v = 0xFFu;
+        uint32_t v = CODE_NONE;
         if (g < 4u && rd < 4u) {
             const uint32_t cell = 4u * rd + g;
             v = (strand ? 15u - cell : cell) << 1;  // bit 0 (table) is OR-ed in per read
         }
         lut[i] = (uint8_t)v;
+    }
+
+    if (tid < 256u) ctxf[tid] = (uint8_t)((in_set(P.up_mask, tid) ? 1u : 0u) | (in_set(P.down_mask, tid) ? 2u : 0u));
+    // bytes of this lane's code-sheet row that lie outside the N+2 live rows stay CODE_NONE:
+    // left end (row = byte) bytes >= n_pos, right end (row = 31 - byte) bytes <= 31 - n_pos
+    uint32_t dead_w[8];
+    {
+        const uint32_t e0 = tid & 1u;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            uint32_t mk = 0u;
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const uint32_t byte = 4u * k + b, row = e0 ? 31u - byte : byte;
+                if (row >= n_pos) mk |= 0xFFu << (8 * b);
+            }
+            dead_w[k] = mk;
+        }
     }
 
     uint32_t my_stats[ST_USED];
@@ -293,22 +336,19 @@ __global__ void __launch_bounds__(TILED_THREADS) tally_tiled(const TallyParams P
         if (next < n_tiles) geom(tgeo[0], tgeo[1], nxt_base16, nxt_staged);
 
         // ---- CODES: lane pair per read ------------------------------------------------------
+        // (TILED_THREADS is even, so a thread keeps the same end e = tid & 1 on every pass)
         for (uint32_t p = tid; p < 2u * T; p += TILED_THREADS) {
             const uint32_t j = p >> 1, e = p & 1u;  // e = 0: left alignment end, 1: right end
             const bool in_tile = j < count;
             uint32_t o0 = 0, o1 = 0;
             if (in_tile) { o0 = toffs[j]; o1 = toffs[j + 1]; }
             const bool in_stage = in_tile && (o1 - cur_base16 <= cur_staged);
-            LdsBytes src{stage + (o0 - cur_base16)};
-            RecHdr h;
-            Plan pl;
-            pl.st_mask = 0u; pl.live = false; pl.pss_cand = pl.pss_fwd = pl.pss_rev = pl.fk5 = pl.fk3 = false;
-            pl.rev = false; pl.L = 0; pl.Lk = 0; pl.s = 0; pl.gbase = 0; pl.flag = 0;
-            h.l_seq = 0; h.seq_off = 0;
-            if (in_stage) {
-                h = decode_hdr(src, o1 - o0);
-                pl = plan_head(P, src, h);
-            }
+            // records outside the tile / the staging window decode a harmless dummy (offset 0, length
+            // 0 -> malformed -> dead) so the lanes of a wave stay on one path
+            LdsBytes src{stage, in_stage ? o0 - cur_base16 : 0u};
+            const RecHdr h = decode_hdr_lds(src, in_stage ? o1 - o0 : 0u);
+            Plan pl = plan_head(P, src, h);
+            if (!in_stage) { pl.st_mask = 0u; pl.live = pl.pss_cand = pl.fk5 = pl.fk3 = false; }
             // this end's reference window, issued for every candidate before the -U/-D test so the
             // test costs no extra memory round trip
             const bool cand = DO_PSS && pl.pss_cand;
@@ -327,21 +367,31 @@ __global__ void __launch_bounds__(TILED_THREADS) tally_tiled(const TallyParams P
             // first context base next to the alignment: left window byte 1 (s-1), right window byte 30 (s+L)
             const uint32_t own1 = e ? (gw[7] >> 16) & 0xFFu : (gw[0] >> 8) & 0xFFu;
             const uint32_t other1 = (uint32_t)__shfl_xor((int)own1, 1);
-            if (DO_PSS && in_stage) plan_finish_pss(P, pl, e ? other1 : own1, e ? own1 : other1);
+            if (DO_PSS && in_stage) plan_finish_pss(P, CtxLds{ctxf}, pl, e ? other1 : own1, e ? own1 : other1);
             uint32_t m = pl.st_mask;
 
             uint32_t code_w[8];
 #pragma unroll
-            for (int k = 0; k < 8; k++) code_w[k] = 0xFFFFFFFFu;
+            for (int k = 0; k < 8; k++) code_w[k] = CODE_NONE * 0x01010101u;
             // this lane's end feeds: left -> fwd table on forward reads, rev table on reverse reads
             const uint32_t tsel = e ^ (pl.rev ? 1u : 0u);
             if (cand && (tsel ? pl.pss_rev : pl.pss_fwd)) {
-                // read bases of this end as a nibble stream: stream nibble q <-> read base n0 + q
-                const int32_t n0 = e ? (int32_t)pl.L - 30 : 0;
+                // read bases of this end as a nibble stream aligned with the window bytes:
+                // stream nibble b <-> read base n0 + b, n0 = -2 (left: bytes 0,1 are context and
+                // their two nibbles are never used) or L-30 (right)
+                const int32_t n0 = e ? (int32_t)pl.L - 30 : -2;
                 const uint32_t sb = (uint32_t)((int32_t)h.seq_off + (n0 >> 1));  // arithmetic shift = floor
                 uint32_t sw[5];
+                {   // 20 bytes from sb as six aligned dwords, one batch
+                    const uint32_t sa = src.off + sb;
+                    const uint32_t ssh = sa & 3u;
+                    const uint32_t *qs = (const uint32_t *)(stage + (sa & ~3u));
+                    uint32_t rr[6];
 #pragma unroll
-                for (int k = 0; k < 5; k++) sw[k] = src.u32(sb + 4u * k);
+                    for (int k = 0; k < 6; k++) rr[k] = qs[k];
+#pragma unroll
+                    for (int k = 0; k < 5; k++) sw[k] = __builtin_amdgcn_alignbyte(rr[k + 1], rr[k], ssh);
+                }
 #pragma unroll
                 for (int k = 0; k < 5; k++)  // high nibble first -> nibble q at bits 4q
                     sw[k] = ((sw[k] & 0x0F0F0F0Fu) << 4) | ((sw[k] >> 4) & 0x0F0F0F0Fu);
@@ -358,18 +408,36 @@ __global__ void __launch_bounds__(TILED_THREADS) tally_tiled(const TallyParams P
                     const uint32_t keep = have >= lo + 8u ? 0xFFFFFFFFu : have > lo ? ((1u << (4u * (have - lo))) - 1u) : 0u;
                     sw[k] &= keep;
                 }
+                // context bytes carry no read base: give them the nibble of their own reference
+                // base, the LUT then yields the diagonal cell (pss-bam.c:172-184).  Left: bytes 0,1;
+                // right: bytes 30,31.
+                {
+                    const uint32_t ca = e ? 30u : 0u;  // first of the two context bytes
+                    const uint32_t ga_ = min((e ? gw[7] >> 16 : gw[0]) & 0xFFu, 3u);
+                    const uint32_t gb_ = min((e ? gw[7] >> 24 : gw[0] >> 8) & 0xFFu, 3u);
+                    const uint32_t two = (1u << ga_) | ((1u << gb_) << 4);  // nibbles for bytes ca, ca+1
+                    const uint32_t word = ca >> 3, sh4 = 4u * (ca & 7u);
+                    // word 0 (left) or word 3 (right), bits [sh4, sh4+8)
+                    if (word == 0u) sw[0] = (sw[0] & ~(0xFFu << sh4)) | (two << sh4);
+                    else sw[3] = (sw[3] & ~(0xFFu << sh4)) | (two << sh4);
+                }
                 const uint8_t *lut_s = lut + (pl.rev ? 136u : 0u);
+                const uint32_t tsel4 = tsel * 0x01010101u;  // CODE_NONE | 1 is a trash row too
 #pragma unroll
-                for (int b = 0; b < 32; b++) {
-                    const uint32_t row = e ? 31u - (uint32_t)b : (uint32_t)b;
-                    if (row < n_pos) {
+                for (int half = 0; half < 2; half++) {  // branch-free: 16 independent LUT reads in flight
+                    uint32_t cb[16];
+#pragma unroll
+                    for (int i = 0; i < 16; i++) {
+                        const int b = 16 * half + i;
                         const uint32_t g = min((gw[b >> 2] >> (8 * (b & 3))) & 0xFFu, 4u);
-                        const int q = e ? b : b - 2;  // stream nibble of this window byte
-                        const uint32_t nib = q >= 0 ? (sw[(q >> 3) & 3] >> (4 * (q & 7))) & 0xFu : 0u;
-                        const uint32_t v = lut_s[(row < 2u ? 16u : nib) * 8u + g];
-                        const uint32_t cb = v == 0xFFu ? 0xFFu : (v | tsel);
-                        code_w[b >> 2] = (code_w[b >> 2] & ~(0xFFu << (8 * (b & 3)))) | (cb << (8 * (b & 3)));
+                        const uint32_t nib = (sw[b >> 3] >> (4 * (b & 7))) & 0xFu;
+                        cb[i] = lut_s[nib * 8u + g];
                     }
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        code_w[4 * half + k] = (((cb[4 * k] | (cb[4 * k + 1] << 8) | (cb[4 * k + 2] << 16) |
+                                                  (cb[4 * k + 3] << 24)) | tsel4) & ~dead_w[4 * half + k]) |
+                                               ((CODE_NONE * 0x01010101u) & dead_w[4 * half + k]);
                 }
             }
             bool kmer_try = false, kmer_ok = true;
@@ -377,16 +445,8 @@ __global__ void __launch_bounds__(TILED_THREADS) tally_tiled(const TallyParams P
                 kmer_try = true;
                 kmer_ok = tally_one_kmer<LDS_KMER>(P, pl, e, lds_kmer);
             }
-            if (in_tile && !in_stage && e == 0u) {
-                // record does not fit the staging window (huge record): whole thing from global,
-                // by the first lane of the pair
-                GlobalBytes gsrc{P.recs + o0};
-                const RecHdr gh = decode_hdr(gsrc, o1 - o0);
-                const Plan gpl = make_plan(P, gsrc, gh);
-                m = gpl.st_mask;
-                if (DO_PSS && (gpl.pss_fwd || gpl.pss_rev)) tally_pss_record(P, LdsTableColumnMajor{table}, gsrc, gh, gpl);
-                if (DO_KMER && (gpl.fk5 || gpl.fk3)) m |= tally_kmer_record<LDS_KMER>(P, gpl, lds_kmer);
-            }
+            if (in_tile && !in_stage && e == 0u)
+                m = tally_overflow_record<DO_PSS, DO_KMER, LDS_KMER>(kernarg, o0, o1, table, lds_kmer);
             // code sheet row of read j: bytes [e*32, e*32+32)
             uint4 *dst = (uint4 *)(sheet + j * 64u + e * 32u);
             dst[0] = make_uint4(code_w[0], code_w[1], code_w[2], code_w[3]);
@@ -421,20 +481,16 @@ __global__ void __launch_bounds__(TILED_THREADS) tally_tiled(const TallyParams P
             const uint32_t row = e ? 31u - b : b;
             const uint32_t per_wave = (count + TILED_WAVES - 1u) / TILED_WAVES;
             const uint32_t j0 = wave * per_wave, j1 = min(count, j0 + per_wave);
-            if (row < n_pos) {
+            if (row < n_pos) {  // (lanes of dead rows would only ever see CODE_NONE)
                 uint32_t j = j0;
                 for (; j + 8u <= j1; j += 8u) {
                     uint32_t c[8];
 #pragma unroll
                     for (int u = 0; u < 8; u++) c[u] = sheet[(j + u) * 64u + lane];
 #pragma unroll
-                    for (int u = 0; u < 8; u++)
-                        if (c[u] != 0xFFu) atomicAdd(&table[(c[u] << 5) + row], 1u);
+                    for (int u = 0; u < 8; u++) atomicAdd(&table[(c[u] << 5) + row], 1u);
                 }
-                for (; j < j1; j++) {
-                    const uint32_t c = sheet[j * 64u + lane];
-                    if (c != 0xFFu) atomicAdd(&table[(c << 5) + row], 1u);
-                }
+                for (; j < j1; j++) atomicAdd(&table[((uint32_t)sheet[j * 64u + lane] << 5) + row], 1u);
             }
         }
     }
@@ -444,7 +500,7 @@ __global__ void __launch_bounds__(TILED_THREADS) tally_tiled(const TallyParams P
         if (my_stats[i]) atomicAdd(&lds_stats[i], my_stats[i]);
     __syncthreads();
     if (DO_PSS) {
-        for (uint32_t i = tid; i < 32u * 32u; i += TILED_THREADS) {
+        for (uint32_t i = tid; i < 32u * 32u; i += TILED_THREADS) {  // code rows 32,33 are the trash bin
             const uint32_t v = table[i];
             const uint32_t row = i & 31u, ct = i >> 5, t = ct & 1u, cell = ct >> 1;
             if (v && row < n_pos)
