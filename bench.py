@@ -186,10 +186,12 @@ def main():
     alg_per_step = total_rec_bytes + per_gpu * (4 + 2 * (region_len + 2) + (2 * klen if klen else 0))
     achieved = alg_per_step * args.steps / (kernel_ms / 1e3) / 1e9 if kernel_ms > 0 else 0.0
     traffic = None
-    tj = ROOT / "profiles" / "traffic.json"   # PMC-derived HBM bytes per launch, collected separately
+    tj = ROOT / "profiles" / "traffic.json"   # PMC-derived HBM bytes per read, collected in separate --pmc passes
     if tj.exists():
         try:
-            traffic = json.loads(tj.read_text()).get(args.config, {}).get("hbm_bytes_per_launch")
+            per_read = json.loads(tj.read_text()).get(args.config, {}).get("hbm_bytes_per_read")
+            if per_read is not None:
+                traffic = per_read * per_gpu / len(blocks)   # per launch, like `achieved`
         except Exception:
             traffic = None
 

@@ -423,7 +423,7 @@ static int launch_tally(pssbam_engine *e, const uint8_t *d_recs, uint64_t nbytes
         // staging window are handled (slowly, correctly) straight from global memory
         const uint64_t avg = std::max<uint64_t>(40, nbytes / n_records);
         uint32_t T = avg * 128 <= 40 * 1024 ? 128u : 64u;
-        if (e->env_tile_reads > 0) T = std::min<uint32_t>(512u, (uint32_t)(e->env_tile_reads + 63) / 64 * 64);
+        if (e->env_tile_reads > 0) T = std::min<uint32_t>(512u, (uint32_t)(e->env_tile_reads + 15) / 16 * 16);
         uint64_t cap64 = (uint64_t)T * avg + (uint64_t)T * avg / 16 + 512;
         cap64 = std::min<uint64_t>(cap64, 64 * 1024);
         if (e->env_tile_cap > 0) cap64 = (uint64_t)e->env_tile_cap;
