@@ -158,6 +158,18 @@ int pssbam_engine_counters_device(pssbam_engine *e, void **d_counters, size_t *n
  * counts are carried over.  NULL returns to the engine's own block. */
 int pssbam_engine_bind_counters(pssbam_engine *e, void *d_counters, size_t n_u64);
 
+/* Node-level sum for one process driving several GPUs (one engine per device): adds the
+ * counter blocks of engines[1..n-1] into engines[root] with ONE RCCL ncclReduce(sum,
+ * uint64) per device inside a group call over xGMI (communicators from ncclCommInitAll,
+ * librccl loaded on first use), after draining every engine's stream.  All engines must
+ * have been created with identical options.  n == 1 is a no-op. */
+int pssbam_reduce_counters(pssbam_engine *const *engines, int n, int root);
+
+/* Page-locks a host range (hipHostRegister) so pssbam_engine_submit's copies from it run as
+ * true async DMA; the front ends register the BAM reader's batch buffer once. */
+int pssbam_host_register(void *ptr, size_t bytes);
+int pssbam_host_unregister(void *ptr);
+
 /* HIP-event stopwatch on the engine's stream: begin records an event, end records a
  * second one, waits for it and returns the elapsed device time in milliseconds. */
 int pssbam_engine_timer_begin(pssbam_engine *e);

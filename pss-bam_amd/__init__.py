@@ -34,7 +34,7 @@ HIP_SYMBOLS = [
     "pssbam_engine_set_stream", "pssbam_engine_set_genome", "pssbam_engine_set_genome_arrays",
     "pssbam_engine_set_references", "pssbam_engine_submit", "pssbam_engine_submit_device", "pssbam_engine_sync",
     "pssbam_engine_finish", "pssbam_engine_reset", "pssbam_engine_counters_device", "pssbam_engine_bind_counters",
-    "pssbam_engine_timer_begin",
+    "pssbam_reduce_counters", "pssbam_host_register", "pssbam_host_unregister", "pssbam_engine_timer_begin",
     "pssbam_engine_timer_end", "pssbam_engine_kernel_time", "pssbam_index_records",
 ]
 

@@ -594,6 +594,98 @@ extern "C" int pssbam_engine_kernel_time(pssbam_engine *e, double *total_ms, uin
 }
 
 // --------------------------------------------------------------------------------------
+// node-level reduce (single process, several devices) over RCCL
+// --------------------------------------------------------------------------------------
+#include <dlfcn.h>
+
+namespace {
+// the handful of RCCL entry points used, resolved from librccl.so on first use so that
+// single-GPU users never pay for loading it
+typedef struct ncclComm *ncclComm_t;
+typedef int (*fn_CommInitAll)(ncclComm_t *, int, const int *);
+typedef int (*fn_CommDestroy)(ncclComm_t);
+typedef int (*fn_GroupStart)(void);
+typedef int (*fn_GroupEnd)(void);
+typedef int (*fn_Reduce)(const void *, void *, size_t, int, int, int, ncclComm_t, hipStream_t);
+typedef const char *(*fn_GetErrorString)(int);
+constexpr int NCCL_UINT64 = 5, NCCL_SUM = 0;  // rccl.h: ncclUint64, ncclSum
+struct Rccl {
+    void *h = nullptr;
+    fn_CommInitAll CommInitAll = nullptr;
+    fn_CommDestroy CommDestroy = nullptr;
+    fn_GroupStart GroupStart = nullptr;
+    fn_GroupEnd GroupEnd = nullptr;
+    fn_Reduce Reduce = nullptr;
+    fn_GetErrorString GetErrorString = nullptr;
+};
+Rccl g_rccl;
+bool load_rccl() {
+    if (g_rccl.h) return true;
+    void *h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return false;
+    g_rccl.CommInitAll = (fn_CommInitAll)dlsym(h, "ncclCommInitAll");
+    g_rccl.CommDestroy = (fn_CommDestroy)dlsym(h, "ncclCommDestroy");
+    g_rccl.GroupStart = (fn_GroupStart)dlsym(h, "ncclGroupStart");
+    g_rccl.GroupEnd = (fn_GroupEnd)dlsym(h, "ncclGroupEnd");
+    g_rccl.Reduce = (fn_Reduce)dlsym(h, "ncclReduce");
+    g_rccl.GetErrorString = (fn_GetErrorString)dlsym(h, "ncclGetErrorString");
+    if (!g_rccl.CommInitAll || !g_rccl.CommDestroy || !g_rccl.GroupStart || !g_rccl.GroupEnd || !g_rccl.Reduce) {
+        dlclose(h);
+        return false;
+    }
+    g_rccl.h = h;
+    return true;
+}
+}  // namespace
+
+extern "C" int pssbam_reduce_counters(pssbam_engine *const *engines, int n, int root) {
+    if (!engines || n < 1 || root < 0 || root >= n) return fail(PSSBAM_EINVAL, "bad argument");
+    for (int i = 0; i < n; i++) {
+        if (!engines[i]) return fail(PSSBAM_EINVAL, "null engine %d", i);
+        if (engines[i]->n_counters != engines[0]->n_counters)
+            return fail(PSSBAM_EINVAL, "engines were created with different options");
+        int rc = pssbam_engine_sync(engines[i]);
+        if (rc) return rc;
+    }
+    if (n == 1) return PSSBAM_OK;
+    if (!load_rccl()) return fail(PSSBAM_EHIP, "librccl.so could not be loaded: %s", dlerror());
+    std::vector<ncclComm_t> comms(n);
+    std::vector<int> devs(n);
+    for (int i = 0; i < n; i++) devs[i] = engines[i]->device;
+    int rc = g_rccl.CommInitAll(comms.data(), n, devs.data());
+    if (rc != 0) return fail(PSSBAM_EHIP, "ncclCommInitAll failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
+    rc = g_rccl.GroupStart();
+    for (int i = 0; i < n && rc == 0; i++) {
+        (void)hipSetDevice(engines[i]->device);
+        rc = g_rccl.Reduce(engines[i]->d_counters, engines[i]->d_counters, engines[i]->n_counters, NCCL_UINT64, NCCL_SUM,
+                           root, comms[i], engines[i]->stream);
+    }
+    const int rc_end = g_rccl.GroupEnd();
+    if (rc == 0) rc = rc_end;
+    for (int i = 0; i < n; i++) {
+        (void)hipSetDevice(engines[i]->device);
+        (void)hipStreamSynchronize(engines[i]->stream);
+    }
+    for (int i = 0; i < n; i++) (void)g_rccl.CommDestroy(comms[i]);
+    if (rc != 0) return fail(PSSBAM_EHIP, "ncclReduce failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
+    return PSSBAM_OK;
+}
+
+extern "C" int pssbam_host_register(void *ptr, size_t bytes) {
+    if (!ptr || !bytes) return fail(PSSBAM_EINVAL, "bad argument");
+    HIP_TRY(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    return PSSBAM_OK;
+}
+
+extern "C" int pssbam_host_unregister(void *ptr) {
+    if (!ptr) return fail(PSSBAM_EINVAL, "bad argument");
+    HIP_TRY(hipHostUnregister(ptr));
+    return PSSBAM_OK;
+}
+
+// --------------------------------------------------------------------------------------
 // host helper: record index
 // --------------------------------------------------------------------------------------
 extern "C" int64_t pssbam_index_records(const void *bytes, uint64_t nbytes, uint32_t *offsets, uint64_t max_records,

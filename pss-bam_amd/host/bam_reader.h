@@ -1,0 +1,48 @@
+/*
+ * pss-bam_amd/host/bam_reader.h -- BGZF / BAM input for the front ends.
+ *
+ * Replaces the `samtools view` child process of the reference (pss-bam.c:148-162,
+ * fragkon.c:84-93): BGZF blocks are inflated by a pool of host threads straight into one
+ * large buffer, and the caller receives blocks of WHOLE raw alignment records plus their
+ * offset index -- exactly what pssbam_engine_submit() wants.  No per-record work happens on
+ * the host beyond following the block_size chain.
+ */
+#ifndef PSSBAM_BAM_READER_H
+#define PSSBAM_BAM_READER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+typedef struct bam_reader bam_reader;
+
+typedef struct bam_header {
+    char *text;            /* SAM header text (not NUL-counted in l_text) */
+    uint32_t l_text;
+    int32_t n_ref;
+    char **ref_name;       /* n_ref names, refID order */
+    uint32_t *ref_len;
+} bam_header;
+
+/* n_threads <= 0: one per online CPU (capped at 32).  batch_bytes: size of the inflated
+ * batch buffer (0 = 256 MiB).  On failure returns NULL and describes it in err. */
+bam_reader *bam_reader_open(const char *path, int n_threads, size_t batch_bytes, char *err, size_t errlen);
+const bam_header *bam_reader_header(const bam_reader *r);
+
+/* Next batch of whole alignment records.  *records points into the reader's own buffer
+ * (valid until the next call), offsets[0..n] index it (offsets[n] == *nbytes).
+ * Returns the record count, 0 at end of file, -1 on error (see bam_reader_error). */
+int64_t bam_reader_next(bam_reader *r, const uint8_t **records, const uint32_t **offsets, size_t *nbytes);
+
+/* The batch buffer, so a caller can page-lock it for DMA (base, capacity). */
+void bam_reader_buffer(const bam_reader *r, void **base, size_t *bytes);
+const char *bam_reader_error(const bam_reader *r);
+double bam_reader_inflate_seconds(const bam_reader *r); /* wall time spent inflating so far */
+void bam_reader_close(bam_reader *r);
+
+/* SAM text of one record (no trailing newline handling surprises: ends with '\n'); returns
+ * bytes written, or -1 if it does not fit.  names = reference names for refID lookup. */
+long bam_record_to_sam(const uint8_t *rec, uint32_t rec_len, const bam_header *h, char *out, size_t cap);
+/* 1 iff the record carries RG:Z:<rg> (host twin of the device-side -R filter) */
+int bam_record_has_rg(const uint8_t *rec, uint32_t rec_len, const char *rg);
+
+#endif

@@ -1,0 +1,117 @@
+/*
+ * pss-bam_amd/host/frontend.c -- the loop that replaces
+ *     popen("samtools view") ; while (fgets) { line2saml ; process_aln }
+ * of the reference (pss-bam.c:760-783, fragkon.c:338-363): inflated BAM record batches go
+ * to the GPU engines as they are, one engine per device, batches dealt round-robin
+ * ("reads shard by record block"); the per-device counter blocks are summed with one RCCL
+ * reduce at the end.
+ */
+#include "frontend.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "bam_reader.h"
+
+static double now_s(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + ts.tv_nsec * 1e-9;
+}
+
+int env_gpu_count(void)
+{
+    const char *v = getenv("PSSBAM_NGPU");
+    int want = v ? atoi(v) : 1, have = pssbam_device_count();
+    if (want < 1) want = 1;
+    if (have < 1) have = 1; /* engine creation reports the real problem */
+    return want > have ? have : want;
+}
+
+void run_result_free(run_result *res)
+{
+    free(res->fwd);
+    free(res->rev);
+    free(res->k5);
+    free(res->k3);
+    memset(res, 0, sizeof *res);
+}
+
+int run_tally(const pssbam_config *cfg, Genome *genome, const char *aln_path, int n_gpus, run_result *res)
+{
+    pssbam_engine *eng[64] = {0};
+    char err[512];
+    int rc = -1, registered = 0;
+    void *buf_base = NULL;
+    size_t buf_bytes = 0;
+    const double t0 = now_s();
+    memset(res, 0, sizeof *res);
+    if (n_gpus < 1) n_gpus = 1;
+    if (n_gpus > 64) n_gpus = 64;
+
+    bam_reader *rd = bam_reader_open(aln_path, 0, 0, err, sizeof err);
+    if (!rd) {
+        fprintf(stderr, "Error: Unable to open %s: %s\n", aln_path, err);
+        return -1;
+    }
+    const bam_header *hdr = bam_reader_header(rd);
+    for (int g = 0; g < n_gpus; g++) {
+        pssbam_config c = *cfg;
+        c.device = g;
+        if (pssbam_engine_create(&c, &eng[g]) || pssbam_engine_set_genome(eng[g], genome) ||
+            pssbam_engine_set_references(eng[g], hdr->n_ref, (const char *const *)hdr->ref_name)) {
+            fprintf(stderr, "Error: GPU engine %d: %s\n", g, pssbam_last_error());
+            goto done;
+        }
+    }
+    bam_reader_buffer(rd, &buf_base, &buf_bytes);
+    registered = pssbam_host_register(buf_base, buf_bytes) == 0; /* best effort: pageable works too */
+
+    for (int turn = 0;; turn++) {
+        const uint8_t *recs;
+        const uint32_t *offs;
+        size_t nbytes;
+        int64_t n = bam_reader_next(rd, &recs, &offs, &nbytes);
+        if (n < 0) {
+            fprintf(stderr, "Error: %s: %s\n", aln_path, bam_reader_error(rd));
+            goto done;
+        }
+        if (n == 0) break;
+        if (pssbam_engine_submit(eng[turn % n_gpus], recs, nbytes, offs, (uint32_t)n)) {
+            fprintf(stderr, "Error: GPU engine: %s\n", pssbam_last_error());
+            goto done;
+        }
+    }
+    if (pssbam_reduce_counters(eng, n_gpus, 0)) {
+        fprintf(stderr, "Error: counter reduce: %s\n", pssbam_last_error());
+        goto done;
+    }
+    if (cfg->tally_mask & PSSBAM_TALLY_PSS) {
+        size_t cells = (size_t)(cfg->pss.region_len + 2) * 16;
+        res->fwd = (unsigned long *)calloc(cells, sizeof(unsigned long));
+        res->rev = (unsigned long *)calloc(cells, sizeof(unsigned long));
+    }
+    if (cfg->tally_mask & PSSBAM_TALLY_KMER) {
+        size_t bins = (size_t)1 << (2 * cfg->kmer.klen);
+        res->k5 = (uint64_t *)calloc(bins, sizeof(uint64_t));
+        res->k3 = (uint64_t *)calloc(bins, sizeof(uint64_t));
+    }
+    if (pssbam_engine_finish(eng[0], res->fwd, res->rev, res->k5, res->k3, res->stats)) {
+        fprintf(stderr, "Error: GPU engine: %s\n", pssbam_last_error());
+        goto done;
+    }
+    res->inflate_s = bam_reader_inflate_seconds(rd);
+    res->n_gpus = n_gpus;
+    rc = 0;
+done:
+    for (int g = 0; g < n_gpus; g++)
+        if (eng[g]) pssbam_engine_destroy(eng[g]);
+    if (registered) pssbam_host_unregister(buf_base);
+    bam_reader_close(rd);
+    res->total_s = now_s() - t0;
+    if (rc) run_result_free(res);
+    return rc;
+}

@@ -1,0 +1,26 @@
+/* pss-bam_amd/host/frontend.h -- what the two command-line front ends share: open the
+ * alignment input, drive one engine per GPU over its record batches, gather the tables. */
+#ifndef PSSBAM_FRONTEND_H
+#define PSSBAM_FRONTEND_H
+
+#include <stdint.h>
+
+#include "fasta-genome-io.h"
+#include "pssbam_hip.h"
+
+typedef struct run_result {
+    unsigned long *fwd, *rev; /* (region_len+2)*16 each, or NULL */
+    uint64_t *k5, *k3;        /* 4^klen each, or NULL            */
+    uint64_t stats[PSSBAM_ST_N];
+    double inflate_s, total_s;
+    int n_gpus;
+} run_result;
+
+/* Streams every alignment of `aln_path` (BGZF BAM) through engines built from `cfg` on
+ * n_gpus devices (batches dealt round-robin), sums the counter blocks onto device 0 with
+ * RCCL when n_gpus > 1, and returns the tables in *res (caller frees with run_result_free).
+ * Returns 0, or -1 after printing a diagnostic to stderr. */
+int run_tally(const pssbam_config *cfg, Genome *genome, const char *aln_path, int n_gpus, run_result *res);
+void run_result_free(run_result *res);
+int env_gpu_count(void); /* PSSBAM_NGPU, default 1, clamped to the devices present */
+#endif

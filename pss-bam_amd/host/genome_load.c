@@ -142,7 +142,12 @@ static int feed(Genome *g, parse_state *ps, const unsigned char *p, size_t n)
     while (i < n) {
         if (ps->state == 0) { /* body: the hot loop */
             Seq *s = ps->cur;
-            if (!s) { ps->bad = 1; return -1; } /* bytes before the first '>' */
+            if (!s) { /* very first byte of the file */
+                if (p[i] != '>') { ps->bad = 1; return -1; } /* precondition: starts with '>' */
+                if (begin_contig(ps)) return -1;
+                i++;
+                continue;
+            }
             while (i < n) {
                 unsigned char c = p[i];
                 unsigned char k = g_class[c];

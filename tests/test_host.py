@@ -1,0 +1,259 @@
+"""CPU tests of the host C side (pss-bam_amd/host): reference-API-compatible modules, the
+BGZF/BAM reader, the report writers and the front ends' error paths.  The oracle and the
+golden vectors are the checkers."""
+import ctypes as C
+import json
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import __graft_entry__ as ge
+import pssbam_testlib as tl
+
+GOLD = Path(__file__).resolve().parent / "golden"
+MANIFEST = json.loads((GOLD / "manifest.json").read_text())
+
+
+@pytest.fixture(scope="module")
+def host():
+    ge.build()
+    pkg = ge.load_pkg()
+    L = C.CDLL(str(pkg.LIB_HOST))
+    L.init_genome.restype = C.c_void_p
+    L.init_genome.argtypes = [C.c_char_p]
+    L.destroy_genome.argtypes = [C.c_void_p]
+    L.find_seq.restype = C.c_void_p
+    L.find_seq.argtypes = [C.c_void_p, C.c_char_p]
+    L.line2saml.argtypes = [C.c_char_p, C.c_void_p]
+    L.aln_seq_len.argtypes = [C.c_char_p]
+    L.init_KSP.restype = C.c_void_p
+    L.add_to_ksp.argtypes = [C.c_char_p, C.c_void_p]
+    L.kmer2count.argtypes = [C.c_char_p, C.c_void_p]
+    L.kmer2count.restype = C.c_uint
+    L.kmer2inx.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.destroy_KSP.argtypes = [C.c_void_p]
+    L.pss_sub_rates.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
+    L.pss_write_counts.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.pss_write_rates.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_void_p, C.c_void_p]
+    return L, pkg
+
+
+class _Seq(C.Structure):
+    _fields_ = [("id", C.c_char * 512), ("seq", C.c_void_p), ("len", C.c_size_t)]
+
+
+class _Genome(C.Structure):
+    _fields_ = [("seqs", C.POINTER(C.POINTER(_Seq))), ("dummy", C.c_void_p), ("n_seqs", C.c_size_t)]
+
+
+def _genome_contents(L, path):
+    g = L.init_genome(str(path).encode())
+    assert g, f"init_genome failed for {path}"
+    G = C.cast(g, C.POINTER(_Genome)).contents
+    out = []
+    for i in range(G.n_seqs):
+        s = G.seqs[i].contents
+        out.append((s.id.decode(), C.string_at(s.seq, s.len), s.len))
+    return g, out
+
+
+@pytest.mark.parametrize("gz", [False, True])
+def test_genome_loader_matches_reference_semantics(host, tmp_path, gz):
+    """upper-casing, whitespace stripping, id = first word, sort by id, '>' splits anywhere"""
+    L, _ = host
+    rng = np.random.default_rng(11)
+    contigs = [("zeta", tl.random_contig(rng, 70001)), ("alpha", tl.random_contig(rng, 333)), ("Mid.1", "acgtNNryACGT"),
+               ("empty", "")]
+    fa = tmp_path / ("g.fa.gz" if gz else "g.fa")
+    tl.write_fasta(fa, contigs, width=61, gz=gz)
+    g, got = _genome_contents(L, fa)
+    want = sorted((cid, seq.upper().encode()) for cid, seq in contigs)
+    assert [(a, b) for a, b, _ in got] == want
+    assert all(n == len(b) for _, b, n in got)
+    # find_seq: exact names only
+    assert L.find_seq(g, b"alpha") and L.find_seq(g, b"zeta") and not L.find_seq(g, b"alph") and not L.find_seq(g, b"*")
+    L.destroy_genome(g)
+
+
+def test_genome_loader_odd_layouts(host, tmp_path, oracle):
+    L, _ = host
+    fa = tmp_path / "odd.fa"
+    # CRLF line ends, blank lines, tabs inside the body, no final newline, '>' glued to a body line
+    fa.write_bytes(b">c1 first\r\nACgt\r\n\r\n ac\tgt \r\n>c2\nTTTT>c3 x\nGGGG\nCC")
+    g, got = _genome_contents(L, fa)
+    assert [(a, b) for a, b, _ in got] == [("c1", b"ACGTACGT"), ("c2", b"TTTT"), ("c3", b"GGGGCC")]
+    L.destroy_genome(g)
+    # malformed inputs are diagnosed (the reference has undefined behaviour on them)
+    bad = tmp_path / "bad.fa"
+    bad.write_bytes(b"ACGT\n>x\nAC\n")
+    assert not L.init_genome(str(bad).encode())
+    assert not L.init_genome(str(tmp_path / "missing.fa").encode())
+
+
+def test_genome_loader_equals_oracle_on_golden(host, oracle):
+    L, _ = host
+    for ds in MANIFEST["datasets"].values():
+        g, got = _genome_contents(L, GOLD / ds["fasta"])
+        txt = (GOLD / ds["fasta"]).read_text()
+        want = sorted((blk.split("\n", 1)[0].split()[0], "".join(blk.split("\n")[1:]).upper().encode())
+                      for blk in txt.split(">")[1:])
+        assert [(a, b) for a, b, _ in got] == want
+        L.destroy_genome(g)
+
+
+SAML_SIZE = 20536
+OFF = dict(qname=0, flag=2048, bits=2052, rname=2054, pos=4104, mapq=4112, cigar=4116, mrnm=6164, mpos=8212, isize=8216,
+           seq_len=8220, seq=8224, qual=10272, tags=12320)
+
+
+def _saml(L, line: str):
+    buf = C.create_string_buffer(SAML_SIZE)
+    rc = L.line2saml(line.encode(), buf)
+    if rc:
+        return rc, None
+    raw = buf.raw
+    cstr = lambda o: raw[o:raw.index(b"\0", o)].decode()  # noqa: E731
+    u32 = lambda o: int.from_bytes(raw[o:o + 4], "little")  # noqa: E731
+    return 0, dict(qname=cstr(OFF["qname"]), flag=u32(OFF["flag"]), bits=int.from_bytes(raw[OFF["bits"]:OFF["bits"] + 2], "little"),
+                   rname=cstr(OFF["rname"]), pos=int.from_bytes(raw[OFF["pos"]:OFF["pos"] + 8], "little"),
+                   mapq=u32(OFF["mapq"]), cigar=cstr(OFF["cigar"]), mrnm=cstr(OFF["mrnm"]), mpos=u32(OFF["mpos"]),
+                   isize=int.from_bytes(raw[OFF["isize"]:OFF["isize"] + 4], "little", signed=True),
+                   seq_len=u32(OFF["seq_len"]), seq=cstr(OFF["seq"]), qual=cstr(OFF["qual"]), tags=cstr(OFF["tags"]))
+
+
+def test_line2saml_fields_and_quirks(host):
+    L, _ = host
+    rc, s = _saml(L, "r1\t83\tchr1\t100\t37\t5M\t=\t90\t-15\tACGTN\tIIIII\tNM:i:1\tRG:Z:x\n")
+    assert rc == 0 and s["qname"] == "r1" and s["flag"] == 83 and s["rname"] == "chr1" and s["pos"] == 100
+    assert s["mapq"] == 37 and s["cigar"] == "5M" and s["mrnm"] == "=" and s["mpos"] == 90 and s["isize"] == -15
+    assert s["seq"] == "ACGTN" and s["qual"] == "IIIII" and s["seq_len"] == 5 and s["tags"] == "NM:i:1\tRG:Z:x\n"
+    assert s["bits"] == 83 & 0xFFF                   # twelve flag bitfields = FLAG bits 0x1..0x800
+    rc, s = _saml(L, "r2\t16\tchr1\t7\t0\t3M\t*\t0\t999\tACG\tIII\n")
+    assert rc == 0 and s["isize"] == 3               # unpaired: isize := strlen(SEQ)  (sam-parse.c:66-68)
+    assert _saml(L, "r3\t0\tchr1\t7\t0\t3M\t*\t0\t0\tACG\t*\n")[0] == 1       # SEQ/QUAL length mismatch
+    assert _saml(L, "r4\t0\tchr1\t7\t0\t3M\t*\t0\t0\tACG\n")[0] == 1           # ten fields
+    assert _saml(L, "@HD\tVN:1.6\n")[0] == 1
+    assert _saml(L, "r5\tx\tchr1\t7\t0\t3M\t*\t0\t0\tACG\tIII\n")[0] == 1     # FLAG not a number
+    rc, s = _saml(L, "r6 0 chr1 7 0 3M * 0 0x10 ACG III\n")                       # blanks separate too; %i reads hex
+    assert rc == 0 and s["pos"] == 7 and s["isize"] == 3 and s["rname"] == "chr1"
+    rc, s = _saml(L, "r7\t1\tchr1\t7\t0\t3M\t*\t0\t0x10\tACG\tIII\n")
+    assert rc == 0 and s["isize"] == 16
+    rc, s = _saml(L, "r8\t-1\tchr1\t7\t0\t3M\t*\t0\t0\tACG\tIII\n")              # %u wraps a negative
+    assert rc == 0 and s["flag"] == 0xFFFFFFFF
+    assert _saml(L, "r9\t0\t" + "c" * 3000 + "\t7\t0\t3M\t*\t0\t0\tACG\tIII\n")[0] == 1   # field > 2047: rejected
+    assert L.aln_seq_len(b"10M2I5M3S") == 15 and L.aln_seq_len(b"*") == 0
+
+
+def test_line2saml_agrees_with_oracle_parser_on_fuzz(host, oracle, tmp_path):
+    """same accept/reject decision and same fields as the oracle's scanf restatement"""
+    L, _ = host
+    _, refs, recs = tl.fuzz_dataset(31, 1200, with_rg=True)
+    lib = oracle.lib
+
+    class Aln(C.Structure):
+        _fields_ = [("rname", C.c_char_p), ("cigar", C.c_char_p), ("seq", C.c_char_p), ("flag", C.c_uint), ("mapq", C.c_uint),
+                    ("pos", C.c_ulong), ("isize", C.c_int), ("seq_len", C.c_int)]
+    lib.orc_parse_line.argtypes = [C.c_char_p, C.POINTER(Aln), C.c_char_p]
+    rng = np.random.default_rng(5)
+    n_ok = 0
+    for r in recs:
+        line = tl.sam_line(r)
+        if rng.random() < 0.05:
+            line = line.replace("\t", " ", int(rng.integers(1, 4)))     # blanks as separators
+        if rng.random() < 0.03:
+            line = "\t".join(line.split("\t")[:int(rng.integers(3, 11))]) + "\n"   # truncated line
+        a = Aln()
+        scratch = C.create_string_buffer(6 * (len(line) + 2))
+        want_rc = lib.orc_parse_line(line.encode(), C.byref(a), scratch)
+        rc, s = _saml(L, line)
+        assert rc == want_rc, line
+        if rc == 0:
+            n_ok += 1
+            assert (s["rname"], s["cigar"], s["seq"]) == (a.rname.decode(), a.cigar.decode(), a.seq.decode())
+            assert (s["flag"], s["mapq"], s["pos"], s["isize"], s["seq_len"]) == (a.flag, a.mapq, a.pos, a.isize, a.seq_len)
+    assert n_ok > 900
+
+
+def test_kmer_table_api(host):
+    L, _ = host
+    for k in (3, 8, 11):
+        ks = L.init_KSP(k)
+        kmers = ["ACGTACGTACGT"[:k], "TTTTTTTTTTTT"[:k], "acgtacgtacgt"[:k]]
+        for km in kmers:
+            assert L.add_to_ksp(km.encode(), ks) == 0
+        assert L.add_to_ksp(("ACGTNCGTACGT"[:k]).encode(), ks) == (-1 if k > 4 else 0)
+        assert L.kmer2count(kmers[0].encode(), ks) == (2 if k > 4 else 3)          # case-folded on add
+        assert L.kmer2count(kmers[1].encode(), ks) == 1 and L.kmer2count(("G" * k).encode(), ks) == 0
+        L.destroy_KSP(ks)
+    inx = C.c_size_t()
+    assert L.kmer2inx(b"ACGT", 4, C.byref(inx)) == 1 and inx.value == 0b00011011
+    assert L.kmer2inx(b"ACNT", 4, C.byref(inx)) == 0
+
+
+@pytest.mark.parametrize("case", [c for c in MANIFEST["cases"] if c["tool"] == "pss-bam"], ids=lambda c: c["prefix"])
+def test_report_writers_byte_exact(host, case, tmp_path):
+    """tables parsed from the reference's counts file -> our writers -> identical files"""
+    L, _ = host
+    ds = MANIFEST["datasets"][case["dataset"]]
+    want_counts = (GOLD / case["counts"]).read_text()
+    fwd, rev = tl.parse_counts_text(want_counts)
+    n = fwd.shape[0] - 2
+    fr, rr = np.zeros((max(n, 1), 12)), np.zeros((max(n, 1), 12))
+    L.pss_sub_rates(n, fwd.ctypes.data, fr.ctypes.data)
+    L.pss_sub_rates(n, rev.ctypes.data, rr.ctypes.data)
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        L.pss_write_counts(ds["fasta"].encode(), ds["sam"].encode(), case["prefix"].encode(), n, fwd.ctypes.data, rev.ctypes.data)
+        L.pss_write_rates(ds["fasta"].encode(), ds["sam"].encode(), case["prefix"].encode(), n, fr.ctypes.data, rr.ctypes.data)
+        assert Path(case["counts"]).read_text() == want_counts
+        assert Path(case["rates"]).read_text() == (GOLD / case["rates"]).read_text()
+    finally:
+        os.chdir(cwd)
+
+
+def test_bam_reader_roundtrip_through_bam2sam(host, tmp_path):
+    """BGZF blocks of random size (records and even length words straddle blocks), several
+    inflate threads, small batch buffer -> text identical to the independent SAM writer"""
+    _, pkg = host
+    exe = pkg.PKG_DIR / "bin" / "bam2sam"
+    for seed, with_rg in ((1, False), (2, True)):
+        _, refs, recs = tl.fuzz_dataset(500 + seed, 3000, with_rg=with_rg)
+        bam = tmp_path / f"x{seed}.bam"
+        tl.write_bam(bam, refs, recs, level=1, rng=np.random.default_rng(seed), block=4000)
+        out = subprocess.run([str(exe), str(bam)], capture_output=True, text=True, check=True).stdout
+        want = "".join(tl.sam_line(r) for r in recs)
+        # BAM cannot tell "RNAME not in header" from '*': the writer maps both to refID -1
+        want = want.replace("\tchrNotInHeader\t", "\t*\t")
+        assert out == want
+        if with_rg:
+            out = subprocess.run([str(exe), "-r", "grpA", str(bam)], capture_output=True, text=True, check=True).stdout
+            assert out == "".join(tl.sam_line(r) for r in recs if ("RG", "Z", "grpA") in r.tags)
+    # golden BAM fixtures decode to their SAM twins
+    for ds in MANIFEST["datasets"].values():
+        out = subprocess.run([str(exe), str(GOLD / ds["bam"])], capture_output=True, text=True, check=True).stdout
+        want = "".join(ln for ln in (GOLD / ds["sam"]).read_text().splitlines(True) if not ln.startswith("@"))
+        assert out == want
+    # corrupt input is diagnosed
+    bad = tmp_path / "bad.bam"
+    data = bytearray((tmp_path / "x1.bam").read_bytes())
+    data[len(data) // 2] ^= 0xFF
+    bad.write_bytes(bytes(data))
+    pr = subprocess.run([str(exe), str(bad)], capture_output=True, text=True)
+    assert pr.returncode != 0 and "bam2sam:" in pr.stderr
+
+
+def test_front_end_argument_handling(host, tmp_path):
+    _, pkg = host
+    pss, fk = pkg.PKG_DIR / "bin" / "pss-bam", pkg.PKG_DIR / "bin" / "fragkon"
+    pr = subprocess.run([str(pss)], capture_output=True, text=True)
+    assert pr.returncode == 1 and pr.stderr.startswith("pss-bam v1.2.1: Program for describing base context")
+    pr = subprocess.run([str(pss), "-F"], capture_output=True, text=True)
+    assert pr.returncode == 0 and "Please enter required argument for option -F." in pr.stderr
+    pr = subprocess.run([str(fk), "-B", "x"], capture_output=True, text=True)
+    assert pr.returncode == 1 and pr.stderr.startswith("fragkon: Program for describing kmer-based")
+    pr = subprocess.run([str(pss), "-F", str(tmp_path / "nope.fa"), "-B", "x.bam", "-o", "o"], capture_output=True, text=True)
+    assert pr.returncode == 1 and "Reading genome sequence from:" in pr.stderr and "Cannot open file" in pr.stderr
