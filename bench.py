@@ -41,6 +41,21 @@ def log(*a):
         print(*a, file=sys.stderr, flush=True)
 
 
+def shard_of(rank: int, world: int, per_gpu: int) -> tuple[int, int, int]:
+    """Weak-scaling shard plan: the stream has per_gpu*world reads; rank r owns the contiguous
+    slot range [r*per_gpu, (r+1)*per_gpu).  Returns (total_reads, first_slot, n_slots)."""
+    return per_gpu * world, rank * per_gpu, per_gpu
+
+
+def reduce_counters(ctr, world: int):
+    """Sums the per-rank counter blocks onto rank 0.  The blocks are u64; they travel as int64
+    (two's complement addition is the same bit pattern), RCCL on GPUs, gloo in the CPU test."""
+    import torch.distributed as dist
+    if world > 1:
+        dist.reduce(ctr, dst=0, op=dist.ReduceOp.SUM)
+    return ctr
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -82,9 +97,8 @@ def main():
     region_len = cd.pop("region_len")
     klen = cd.pop("klen", None)
     per_gpu = args.reads if args.reads is not None else cd["n_reads"]
-    cd["n_reads"] = per_gpu * world
+    cd["n_reads"], slot0, _ = shard_of(rank, world, per_gpu)
     cfg = synth.make_cfg(**cd)
-    slot0 = rank * per_gpu
     S = synth.lib()
     stream = torch.cuda.current_stream().cuda_stream
     n_contigs = int(cfg.n_contigs)
@@ -154,8 +168,7 @@ def main():
         ctr.zero_()
         for rt, ot, nbytes, n in blocks:
             eng.submit_device(rt.data_ptr(), nbytes, ot.data_ptr(), n)
-        if world > 1:
-            dist.reduce(ctr, dst=0, op=dist.ReduceOp.SUM)  # u64 sums == i64 sums bit for bit
+        reduce_counters(ctr, world)
 
     def fence():
         torch.cuda.synchronize()

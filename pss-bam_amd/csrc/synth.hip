@@ -11,6 +11,8 @@
 #include <thread>
 #include <vector>
 
+#include <zlib.h>
+
 #include "synth_model.h"
 
 // ---------------------------------------------------------------------------------------
@@ -212,6 +214,88 @@ int synth_fasta_host(const synth_cfg *c, const char *path, uint32_t first, uint3
         if (col) fputc('\n', f);
     }
     return fclose(f) == 0 ? 0 : -1;
+}
+
+// A complete BGZF-compressed BAM file holding slots [slot0, slot0+n) (header with the contig
+// list, then the records), deflated by `threads` workers.  level 0..9 (1 = fast).  This is the
+// on-disk form the front ends consume; used by the end-to-end measurements and CLI tests.
+int synth_bam_file_host(const synth_cfg *c, uint64_t slot0, uint64_t n, const char *path, int level, int threads) {
+    FILE *f = fopen(path, "wb");
+    if (!f) return -1;
+    // header bytes
+    std::string head;
+    {
+        std::string text = "@HD\tVN:1.6\tSO:" + std::string(c->sorted ? "coordinate" : "unsorted") + "\n";
+        char nm[16];
+        for (uint32_t k = 0; k < c->n_contigs; k++) {
+            contig_name(c, k, nm);
+            text += "@SQ\tSN:" + std::string(nm) + "\tLN:" + std::to_string(c->contig_len[k]) + "\n";
+        }
+        auto put32 = [&](uint32_t v) { for (int i = 0; i < 4; i++) head.push_back((char)(v >> (8 * i))); };
+        head += "BAM\1";
+        put32((uint32_t)text.size());
+        head += text;
+        put32(c->n_contigs);
+        for (uint32_t k = 0; k < c->n_contigs; k++) {
+            contig_name(c, k, nm);
+            put32((uint32_t)strlen(nm) + 1);
+            head.append(nm, strlen(nm) + 1);
+            put32((uint32_t)c->contig_len[k]);
+        }
+    }
+    const uint64_t CHUNK_READS = 1u << 18;  // records generated + compressed per round
+    const size_t BLK = 0xFF00;
+    std::vector<uint8_t> raw, carry(head.begin(), head.end());
+    std::vector<uint32_t> sizes, offs;
+    int rc = 0;
+    for (uint64_t a = 0; a < n || !carry.empty(); a += CHUNK_READS) {
+        const uint64_t m = a < n ? std::min<uint64_t>(CHUNK_READS, n - a) : 0;
+        sizes.resize(m);
+        offs.resize(m + 1);
+        if (m) synth_sizes_host(c, slot0 + a, m, sizes.data(), threads);
+        uint64_t tot = 0;
+        for (uint64_t i = 0; i < m; i++) { offs[i] = (uint32_t)tot; tot += sizes[i]; }
+        offs[m] = (uint32_t)tot;
+        raw.resize(carry.size() + tot);
+        std::copy(carry.begin(), carry.end(), raw.begin());
+        if (m) synth_records_host(c, slot0 + a, m, offs.data(), raw.data() + carry.size(), threads);
+        const bool last = a + m >= n;
+        // whole BGZF blocks now, remainder carried (flushed on the last round)
+        const size_t n_blk = last ? (raw.size() + BLK - 1) / BLK : raw.size() / BLK;
+        std::vector<std::vector<uint8_t>> out(n_blk);
+        parallel_for(n_blk, threads, [&](uint64_t b0, uint64_t b1) {
+            z_stream zs;
+            for (uint64_t b = b0; b < b1; b++) {
+                const size_t o = b * BLK, len = std::min(BLK, raw.size() - o);
+                memset(&zs, 0, sizeof zs);
+                deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
+                std::vector<uint8_t> &dst = out[b];
+                dst.resize(18 + deflateBound(&zs, len) + 8);
+                zs.next_in = raw.data() + o;
+                zs.avail_in = (uInt)len;
+                zs.next_out = dst.data() + 18;
+                zs.avail_out = (uInt)(dst.size() - 26);
+                deflate(&zs, Z_FINISH);
+                const size_t clen = zs.total_out;
+                deflateEnd(&zs);
+                const uint8_t hdr[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
+                memcpy(dst.data(), hdr, 16);
+                const uint32_t bsize = (uint32_t)(clen + 25), crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), raw.data() + o, (uInt)len);
+                dst[16] = (uint8_t)bsize; dst[17] = (uint8_t)(bsize >> 8);
+                uint8_t *t = dst.data() + 18 + clen;
+                for (int i = 0; i < 4; i++) { t[i] = (uint8_t)(crc >> (8 * i)); t[4 + i] = (uint8_t)((uint32_t)len >> (8 * i)); }
+                dst.resize(18 + clen + 8);
+            }
+        });
+        for (auto &d : out)
+            if (fwrite(d.data(), 1, d.size(), f) != d.size()) rc = -1;
+        carry.assign(raw.begin() + std::min(raw.size(), n_blk * BLK), raw.end());
+        if (last) break;
+    }
+    static const uint8_t eof_blk[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (fwrite(eof_blk, 1, 28, f) != 28) rc = -1;
+    if (fclose(f) != 0) rc = -1;
+    return rc;
 }
 
 }  // extern "C"
