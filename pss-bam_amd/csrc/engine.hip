@@ -80,7 +80,8 @@ struct pssbam_engine {
     // genome
     uint8_t *d_genome = nullptr;
     uint64_t genome_bytes = 0;
-    uint64_t *d_contig_start = nullptr, *d_contig_len = nullptr;
+    uint64_t *d_contig_start = nullptr;
+    uint32_t *d_contig_len = nullptr;
     std::vector<std::string> contig_ids;  // sorted by strcmp, like Genome.seqs
     int32_t star_contig = -1;
     // references
@@ -248,12 +249,16 @@ extern "C" int pssbam_engine_set_genome_arrays(pssbam_engine *e, size_t n, const
     std::vector<size_t> order(n);
     for (size_t i = 0; i < n; i++) order[i] = i;
     std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return strcmp(ids[a], ids[b]) < 0; });
-    std::vector<uint64_t> start(n), len(n);
+    std::vector<uint64_t> start(n + 1, 0);
+    std::vector<uint32_t> len(n + 1, 0);
     uint64_t total = CONTIG_PAD;
     for (size_t k = 0; k < n; k++) {
+        if (lens[order[k]] > 0xFFFFFF00ull)
+            return fail(PSSBAM_EINVAL, "contig %s has %llu bases; the engine addresses contigs below 4 Gi bases", ids[order[k]],
+                        (unsigned long long)lens[order[k]]);
         start[k] = total;
-        len[k] = lens[order[k]];
-        total += (len[k] + CONTIG_PAD + CONTIG_ALIGN - 1) / CONTIG_ALIGN * CONTIG_ALIGN;
+        len[k] = (uint32_t)lens[order[k]];
+        total += ((uint64_t)len[k] + CONTIG_PAD + CONTIG_ALIGN - 1) / CONTIG_ALIGN * CONTIG_ALIGN;
     }
     if (e->d_genome) { HIP_TRY(hipFree(e->d_genome)); e->d_genome = nullptr; }
     if (e->d_contig_start) { HIP_TRY(hipFree(e->d_contig_start)); e->d_contig_start = nullptr; }
@@ -271,9 +276,9 @@ extern "C" int pssbam_engine_set_genome_arrays(pssbam_engine *e, size_t n, const
     hipLaunchKernelGGL(encode_genome_kernel, dim3(4096), dim3(256), 0, e->stream, e->d_genome, total / 16);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMalloc(&e->d_contig_start, (n + 1) * sizeof(uint64_t)));
-    HIP_TRY(hipMalloc(&e->d_contig_len, (n + 1) * sizeof(uint64_t)));
-    HIP_TRY(hipMemcpyAsync(e->d_contig_start, start.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(hipMemcpyAsync(e->d_contig_len, len.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMalloc(&e->d_contig_len, (n + 1) * sizeof(uint32_t)));
+    HIP_TRY(hipMemcpyAsync(e->d_contig_start, start.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->d_contig_len, len.data(), (n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     e->genome_bytes = total;
     e->contig_ids.clear();
@@ -380,8 +385,9 @@ static int launch_tally(pssbam_engine *e, const uint8_t *d_recs, uint64_t nbytes
     if (do_pss) {
         P.N = c.pss.region_len;
         P.pss_min_mq = (uint32_t)c.pss.min_mq;
-        P.pss_min_len = c.pss.min_read_len;
-        P.pss_max_len = c.pss.max_read_len;
+        P.pss_len_never = c.pss.min_read_len > 0xFFFFFFFFull ? 1u : 0u;
+        P.pss_min_len = (uint32_t)std::min<uint64_t>(c.pss.min_read_len, 0xFFFFFFFFull);
+        P.pss_max_len = (uint32_t)std::min<uint64_t>(c.pss.max_read_len, 0xFFFFFFFFull);
         P.pss_merged_only = c.pss.merged_only ? 1u : 0u;
         ctx_mask(e->up_ctx.c_str(), P.up_mask);
         ctx_mask(e->down_ctx.c_str(), P.down_mask);
@@ -389,8 +395,9 @@ static int launch_tally(pssbam_engine *e, const uint8_t *d_recs, uint64_t nbytes
     if (do_kmer) {
         P.K = c.kmer.klen;
         P.fk_min_mq = (uint32_t)c.kmer.min_mq;
-        P.fk_min_len = c.kmer.min_read_len;
-        P.fk_max_len = c.kmer.max_read_len;
+        P.fk_len_never = c.kmer.min_read_len > 0xFFFFFFFFull ? 1u : 0u;
+        P.fk_min_len = (uint32_t)std::min<uint64_t>(c.kmer.min_read_len, 0xFFFFFFFFull);
+        P.fk_max_len = (uint32_t)std::min<uint64_t>(c.kmer.max_read_len, 0xFFFFFFFFull);
         P.fk_merged_only = c.kmer.merged_only ? 1u : 0u;
     }
     P.rg = e->has_rg ? e->d_rg : nullptr;
@@ -423,14 +430,15 @@ static int launch_tally(pssbam_engine *e, const uint8_t *d_recs, uint64_t nbytes
         // staging window are handled (slowly, correctly) straight from global memory
         const uint64_t avg = std::max<uint64_t>(40, nbytes / n_records);
         uint32_t T = avg * 128 <= 40 * 1024 ? 128u : 64u;
-        if (e->env_tile_reads > 0) T = std::min<uint32_t>(512u, (uint32_t)(e->env_tile_reads + 15) / 16 * 16);
+        if (e->env_tile_reads > 0) T = std::min<uint32_t>(TILED_MAX_T, (uint32_t)(e->env_tile_reads + 15) / 16 * 16);
         uint64_t cap64 = (uint64_t)T * avg + (uint64_t)T * avg / 16 + 512;
         cap64 = std::min<uint64_t>(cap64, 64 * 1024);
         if (e->env_tile_cap > 0) cap64 = (uint64_t)e->env_tile_cap;
         P.reads_per_tile = T;
+        P.ablate = (uint32_t)env_int("PSSBAM_ABLATE");
         P.tile_bytes_cap = (uint32_t)((cap64 + 1023) & ~1023ull);
         const bool kmer_lds = do_kmer && c.kmer.klen <= KMER_LDS_MAX_K;
-        const uint32_t lds = tiled_lds_bytes(T, P.tile_bytes_cap, kmer_lds, c.kmer.klen);
+        const uint32_t lds = tiled_lds_bytes(P.tile_bytes_cap);
         const uint32_t n_tiles = (n_records + T - 1) / T;
         int occ = 0, rc = PSSBAM_OK;
         const int mult = e->env_grid_mult > 0 ? e->env_grid_mult : 1;

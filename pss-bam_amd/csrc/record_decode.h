@@ -32,21 +32,22 @@ struct TallyParams {
     uint32_t n_recs;
     uint32_t tally_mask;          // PSSBAM_TALLY_*
     const uint8_t *genome;        // all contigs, 1 stored byte/base (enc_byte), padded between
-    const uint64_t *contig_start; // per genome contig (sorted-id order)
-    const uint64_t *contig_len;
+    const uint64_t *contig_start; // per genome contig (sorted-id order), one spare entry
+    const uint32_t *contig_len;   // contigs are < 4 Gi bases (the reference caps them at 536870911)
     const int32_t *ref_map;       // BAM refID -> genome contig, -1 = find_seq fails
     int32_t n_ref;
     int32_t star_contig;          // contig literally named "*" (refID -1), normally -1
     // pss-bam options (pss-bam.c:12-18)
     int32_t N;
     uint32_t pss_min_mq;
-    uint64_t pss_min_len, pss_max_len;
+    uint32_t pss_min_len, pss_max_len;  // clamped to u32 on the host (L is a u32)
+    uint32_t pss_len_never;             // -l beyond any u32: no length can pass
     uint32_t pss_merged_only;
     uint32_t up_mask[8], down_mask[8];  // strchr(UP_CTX/DOWN_CTX, c) as 256-bit sets over STORED bytes
     // fragkon options (fragkon.c:14-18)
     int32_t K;
     uint32_t fk_min_mq;
-    uint64_t fk_min_len, fk_max_len;
+    uint32_t fk_min_len, fk_max_len, fk_len_never;
     uint32_t fk_merged_only;
     // -R read group (NULL = keep all)
     const uint8_t *rg;
@@ -57,9 +58,13 @@ struct TallyParams {
     // tiled kernel geometry
     uint32_t reads_per_tile;      // T, multiple of 64
     uint32_t tile_bytes_cap;      // bytes of the staging buffer, multiple of 1024
+    uint32_t ablate;              // diagnostics: phases to skip (results are wrong when non-zero)
 };
 
-// stats slots, must match include/pssbam_hip.h
+// stats slots, must match include/pssbam_hip.h.  The kernels count EVENTS only: every launch
+// credits n_recs to RECORDS / PSS_OK / KMER_OK up front and each record that ends otherwise moves
+// one unit from the OK slot(s) to its own slot (wrapping u64 arithmetic), so the common case
+// costs no instruction at all.
 enum { ST_RECORDS = 0, ST_RG_DROPPED, ST_PARSE_SKIP, ST_NO_CONTIG, ST_PSS_OK, ST_PSS_FILTERED,
        ST_KMER_OK, ST_KMER_FILTERED, ST_KMER_FAIL, ST_USED };
 
@@ -254,11 +259,14 @@ __device__ __forceinline__ uint32_t read_nibble(const Src &src, const RecHdr &h,
 }
 
 // ---- what to do with one record ---------------------------------------------------------
+// status of a record, as the reference's main loops would classify it
+enum : uint32_t { RS_LIVE = 0, RS_RG_DROPPED = 1, RS_PARSE_SKIP = 2, RS_NO_CONTIG = 3 };
+
 struct Plan {
-    uint32_t st_mask;        // bit per stats slot this record increments (pss bits added by finish)
+    uint32_t status;         // RS_*
     bool live;               // record reached process_aln with a known contig
     uint64_t gbase;          // genome offset of the contig's first base
-    int64_t s;               // 0-based alignment start
+    int32_t s;               // 0-based alignment start (BAM pos)
     bool rev;                // FLAG 0x10
     uint32_t flag;
     // pss
@@ -270,10 +278,10 @@ struct Plan {
     uint32_t Lk;             // strlen(SEQ)
 };
 
-// Text-equivalence + contig lookup + both tools' filters, everything that can be decided
-// from the record alone.  No genome access.  Written as straight-line predicated code (the
-// lanes of a wave hold different records; early returns would only serialise them).
-template <class Src>
+// Text-equivalence + contig lookup + the filters of the enabled tool(s), everything that can be
+// decided from the record alone.  No genome access.  Straight-line predicated code in 32-bit
+// arithmetic (the lanes of a wave hold different records; early returns would only serialise).
+template <bool DO_PSS, bool DO_KMER, class Src>
 __device__ __forceinline__ Plan plan_head(const TallyParams &P, const Src &src, const RecHdr &h) {
     Plan pl;
     pl.pss_fwd = pl.pss_rev = false;
@@ -285,56 +293,53 @@ __device__ __forceinline__ Plan plan_head(const TallyParams &P, const Src &src, 
     // line2saml: strlen(SEQ) vs strlen(QUAL)  (sam-parse.c:50)
     const uint32_t l_text = h.l_seq ? h.l_seq : 1u;
     const uint32_t q0 = (h.well_formed && h.l_seq) ? src.u8(h.qual_off) : 0xFFu;
-    const bool qual_star = (h.l_seq == 0) || (q0 == 0xFFu);
-    const bool parse_skip = !rg_drop && (!h.well_formed || (qual_star && l_text != 1u));
+    const bool parse_skip = !h.well_formed || (q0 == 0xFFu && l_text != 1u);
 
     // find_seq(genome, RNAME)  (pss-bam.c:393-396, fragkon.c:124-127); tables have one spare entry
-    const bool rid_ok = h.ref_id >= 0 && h.ref_id < P.n_ref;
+    const bool rid_ok = (uint32_t)h.ref_id < (uint32_t)P.n_ref;
     const int32_t mapped = P.ref_map[rid_ok ? h.ref_id : 0];
     const int32_t contig = rid_ok ? mapped : (h.ref_id == -1 ? P.star_contig : -1);
-    const bool parsed = !rg_drop && !parse_skip;
-    const bool live = parsed && contig >= 0;
-    const uint64_t glen = P.contig_len[contig >= 0 ? contig : 0];
-    pl.gbase = P.contig_start[contig >= 0 ? contig : 0];
+    const uint32_t cidx = contig >= 0 ? (uint32_t)contig : 0u;
+    const uint32_t glen = P.contig_len[cidx];
+    pl.gbase = P.contig_start[cidx];
+    pl.status = rg_drop ? RS_RG_DROPPED : parse_skip ? RS_PARSE_SKIP : contig < 0 ? RS_NO_CONTIG : RS_LIVE;
+    const bool live = pl.status == RS_LIVE;
     pl.live = live;
     pl.s = h.pos;  // POS-1
     pl.rev = (h.flag & FL_REVERSE) != 0;
-    pl.st_mask = (1u << ST_RECORDS) | (rg_drop ? 1u << ST_RG_DROPPED : 0u) | (parse_skip ? 1u << ST_PARSE_SKIP : 0u) |
-                 ((parsed && contig < 0) ? 1u << ST_NO_CONTIG : 0u);
     const bool paired = (h.flag & FL_PAIRED) != 0;
+    // cigar_ok: exactly "<len>M"; flags: none of 0x4 0x100 0x200 0x400 0x800; s >= 0 (the `s >= 2`
+    // / `s >= k/2` tests below imply it); both tools share these
+    const bool common = live && h.n_cigar == 1u && (h.cigar0 & 0xFu) == 0u && !(h.flag & FL_REJECT) && h.pos >= 0;
     const uint32_t op_len = h.cigar0 >> 4;
-    const bool single_m = (h.n_cigar == 1) && ((h.cigar0 & 0xFu) == 0u);  // cigar_ok: "<len>M"
-    const bool flags_ok = !(h.flag & FL_REJECT);
-    const bool pair_ok = (h.flag & FL_PROPER) && !(h.flag & FL_MUNMAP);
+    const uint32_t s = (uint32_t)h.pos;
+    const bool pair_ok = (h.flag & (FL_PROPER | FL_MUNMAP)) == FL_PROPER;
 
-    {   // process_aln filters, pss-bam.c:401-420
+    pl.L = pl.Lk = l_text;
+    pl.pss_cand = pl.fk5 = pl.fk3 = false;
+    if (DO_PSS) {  // process_aln filters, pss-bam.c:401-420
         const uint32_t L = paired ? (uint32_t)(h.tlen < 0 ? -(int64_t)h.tlen : (int64_t)h.tlen) : l_text;
         pl.L = L;
-        bool ok = live && (P.tally_mask & 1u) && glen > 0 && pl.s >= 2 && (uint64_t)(pl.s + (int64_t)L + 2) <= glen;
+        // s >= 2 && s + L + 2 <= glen, without overflow: L <= glen - 4 first (op_len == L < 2^28)
+        bool ok = common && op_len == L && glen >= 4u && L <= glen - 4u && s - 2u <= glen - 4u - L;
         ok = ok && !(h.mapq < P.pss_min_mq);
-        ok = ok && (uint64_t)L >= P.pss_min_len && (uint64_t)L <= P.pss_max_len && (int64_t)L >= (int64_t)P.N;
-        ok = ok && single_m && op_len == L;
-        ok = ok && flags_ok && !(P.pss_merged_only && paired);
+        ok = ok && !P.pss_len_never && L >= P.pss_min_len && L <= P.pss_max_len && L >= (uint32_t)P.N;
+        ok = ok && !(P.pss_merged_only && paired);
         // paired reads additionally need proper_pair && !munmap and a mate number (:450-452,:460,:471)
         ok = ok && (!paired || (pair_ok && (h.flag & (FL_READ1 | FL_READ2))));
         pl.pss_cand = ok;
     }
-    {   // process_aln filters, fragkon.c:129-146 (+ precondition P4: start >= k/2)
-        const uint32_t L = l_text;
-        const uint32_t okk = (uint32_t)P.K / 2u;
-        pl.Lk = L;
-        bool ok = live && (P.tally_mask & 2u) && glen > 0 && pl.s >= (int64_t)okk &&
-                  (uint64_t)(pl.s + (int64_t)L + okk) <= glen;
+    if (DO_KMER) {  // process_aln filters, fragkon.c:129-146 (+ precondition P4: start >= k/2)
+        const uint32_t L = l_text, okk = (uint32_t)P.K / 2u;
+        // s >= k/2 && s + L + k/2 <= glen
+        bool ok = common && op_len == L && glen >= 2u * okk && L <= glen - 2u * okk && s - okk <= glen - 2u * okk - L;
         ok = ok && h.mapq >= P.fk_min_mq;
-        ok = ok && (uint64_t)L >= P.fk_min_len && (uint64_t)L <= P.fk_max_len;
-        ok = ok && single_m && op_len == L;
-        ok = ok && flags_ok;
+        ok = ok && !P.fk_len_never && L >= P.fk_min_len && L <= P.fk_max_len;
         // unpaired: both ends (:149-183, no -m test); paired: needs !MERGED_ONLY && proper && !munmap,
         // read1 -> 5' only, else read2 -> 3' only (:187-213)
         const bool pok = ok && paired && !P.fk_merged_only && pair_ok;
         pl.fk5 = (ok && !paired) || (pok && (h.flag & FL_READ1));
         pl.fk3 = (ok && !paired) || (pok && !(h.flag & FL_READ1) && (h.flag & FL_READ2));
-        if (live && (P.tally_mask & 2u) && !pl.fk5 && !pl.fk3) pl.st_mask |= 1u << ST_KMER_FILTERED;
     }
     return pl;
 }
@@ -353,37 +358,76 @@ struct CtxLds {  // 256-byte LDS table: bit 0 = in UP_CTX, bit 1 = in DOWN_CTX
 
 // The -U / -D context test and the table choice (pss-bam.c:134-142, :428-494).
 // left1 / right1 = STORED genome bytes at s-1 and s+L (first context base on each side of
-// the alignment, reference orientation).  Adds the pss stats bit.
+// the alignment, reference orientation).
 template <class Ctx>
-__device__ __forceinline__ void plan_finish_pss(const TallyParams &P, const Ctx &ctx, Plan &pl, uint32_t left1,
-                                                uint32_t right1) {
-    if (!(P.tally_mask & 1u)) return;
-    if (pl.live && pl.pss_cand) {
-        // first context base each side, in read orientation (reverse reads: revcomp'ed window)
-        const uint32_t up = pl.rev ? comp_stored(right1) : left1;
-        const uint32_t dn = pl.rev ? comp_stored(left1) : right1;
-        const bool up_ok = ctx.up(up), dn_ok = ctx.down(dn);
-        if (!(pl.flag & FL_PAIRED)) {
-            pl.pss_fwd = pl.pss_rev = up_ok && dn_ok;                              // :428-447
-        } else {                                                                   // :450-494
-            if ((pl.flag & FL_READ1) && up_ok) pl.pss_fwd = true;
-            else if ((pl.flag & FL_READ2) && dn_ok) pl.pss_rev = true;
-        }
+__device__ __forceinline__ void plan_finish_pss(const Ctx &ctx, Plan &pl, uint32_t left1, uint32_t right1) {
+    // first context base each side, in read orientation (reverse reads: revcomp'ed window)
+    const uint32_t up = pl.rev ? comp_stored(right1) : left1;
+    const uint32_t dn = pl.rev ? comp_stored(left1) : right1;
+    const bool up_ok = ctx.up(up), dn_ok = ctx.down(dn);
+    const bool paired = (pl.flag & FL_PAIRED) != 0;
+    const bool r1 = (pl.flag & FL_READ1) != 0, r2 = (pl.flag & FL_READ2) != 0;
+    // unpaired: both tables, both tests (:428-447); paired: read1 && up -> fwd only, else
+    // read2 && down -> rev only (:450-494)
+    pl.pss_fwd = pl.pss_cand && (paired ? (r1 && up_ok) : (up_ok && dn_ok));
+    pl.pss_rev = pl.pss_cand && (paired ? (!(r1 && up_ok) && r2 && dn_ok) : (up_ok && dn_ok));
+}
+
+// Event mask of one fully planned record (bits = stats slots that are NOT the OK outcome).
+// kmer_result: 0 ok / not enabled, 1 = an attempted k-mer add hit a non-ACGT base.
+__device__ __forceinline__ uint32_t record_events(bool DO_PSS, bool DO_KMER, const Plan &pl, bool kmer_failed) {
+    uint32_t ev = 0u;
+    if (pl.status == RS_RG_DROPPED) ev |= 1u << ST_RG_DROPPED;
+    if (pl.status == RS_PARSE_SKIP) ev |= 1u << ST_PARSE_SKIP;
+    if (pl.status == RS_NO_CONTIG) ev |= 1u << ST_NO_CONTIG;
+    if (DO_PSS && pl.live && !(pl.pss_fwd || pl.pss_rev)) ev |= 1u << ST_PSS_FILTERED;
+    if (DO_KMER && pl.live && !(pl.fk5 || pl.fk3)) ev |= 1u << ST_KMER_FILTERED;
+    if (DO_KMER && pl.live && kmer_failed) ev |= 1u << ST_KMER_FAIL;
+    return ev;
+}
+
+// Books a record's events into an LDS array of signed deltas (flushed as wrapping u64 adds).
+__device__ __forceinline__ void book_events(bool DO_PSS, bool DO_KMER, uint32_t ev, int32_t *lds_delta) {
+    if (ev == 0u) return;  // the common case: nothing to do
+    if (ev & (1u << ST_RG_DROPPED)) atomicAdd(&lds_delta[ST_RG_DROPPED], 1);
+    if (ev & (1u << ST_PARSE_SKIP)) atomicAdd(&lds_delta[ST_PARSE_SKIP], 1);
+    if (ev & (1u << ST_NO_CONTIG)) atomicAdd(&lds_delta[ST_NO_CONTIG], 1);
+    const bool dead = (ev & ((1u << ST_RG_DROPPED) | (1u << ST_PARSE_SKIP) | (1u << ST_NO_CONTIG))) != 0;
+    if (DO_PSS) {
+        if (ev & (1u << ST_PSS_FILTERED)) atomicAdd(&lds_delta[ST_PSS_FILTERED], 1);
+        if (dead || (ev & (1u << ST_PSS_FILTERED))) atomicAdd(&lds_delta[ST_PSS_OK], -1);
     }
-    if (pl.live) pl.st_mask |= (pl.pss_fwd || pl.pss_rev) ? (1u << ST_PSS_OK) : (1u << ST_PSS_FILTERED);
+    if (DO_KMER) {
+        if (ev & (1u << ST_KMER_FILTERED)) atomicAdd(&lds_delta[ST_KMER_FILTERED], 1);
+        if (ev & (1u << ST_KMER_FAIL)) atomicAdd(&lds_delta[ST_KMER_FAIL], 1);
+        if (dead || (ev & ((1u << ST_KMER_FILTERED) | (1u << ST_KMER_FAIL)))) atomicAdd(&lds_delta[ST_KMER_OK], -1);
+    }
+}
+
+// Flush of the per-workgroup deltas; block 0 also credits the launch's record count.
+__device__ __forceinline__ void flush_events(bool DO_PSS, bool DO_KMER, const TallyParams &P, const int32_t *lds_delta) {
+    for (uint32_t i = threadIdx.x; i < (uint32_t)ST_USED; i += blockDim.x) {
+        long long d = lds_delta[i];
+        if (blockIdx.x == 0) {
+            if (i == ST_RECORDS || (DO_PSS && i == ST_PSS_OK) || (DO_KMER && i == ST_KMER_OK)) d += P.n_recs;
+        }
+        if (d) atomicAdd(&P.counters[P.off_stats + i], (unsigned long long)d);
+    }
 }
 
 // both steps with the two context bytes fetched from global memory (lane-per-read kernels)
-template <class Src>
+template <bool DO_PSS, bool DO_KMER, class Src>
 __device__ Plan make_plan(const TallyParams &P, const Src &src, const RecHdr &h) {
-    Plan pl = plan_head(P, src, h);
-    uint32_t l1 = 0, r1 = 0;
-    if (pl.pss_cand) {
-        const uint8_t *G = P.genome + pl.gbase;
-        l1 = G[pl.s - 1];
-        r1 = G[pl.s + pl.L];
+    Plan pl = plan_head<DO_PSS, DO_KMER>(P, src, h);
+    if (DO_PSS) {
+        uint32_t l1 = 0, r1 = 0;
+        if (pl.pss_cand) {
+            const uint8_t *G = P.genome + pl.gbase;
+            l1 = G[(int64_t)pl.s - 1];
+            r1 = G[(int64_t)pl.s + pl.L];
+        }
+        plan_finish_pss(CtxMasks{P}, pl, l1, r1);
     }
-    plan_finish_pss(P, CtxMasks{P}, pl, l1, r1);
     return pl;
 }
 
@@ -405,9 +449,9 @@ __device__ __forceinline__ bool kmer_bin(const uint8_t *G, int64_t w0, int K, bo
 }
 
 __device__ __forceinline__ void kmer_windows(const Plan &pl, int K, int64_t &w5, int64_t &w3) {
-    const int64_t ok = K / 2, ik = K - K / 2;
-    if (!pl.rev) { w5 = pl.s - ok; w3 = pl.s + (int64_t)pl.Lk - ik; }
-    else { w5 = pl.s + (int64_t)pl.Lk - ok; w3 = pl.s - ok + (ik - ok); }
+    const int64_t ok = K / 2, ik = K - K / 2, s = pl.s;
+    if (!pl.rev) { w5 = s - ok; w3 = s + (int64_t)pl.Lk - ik; }
+    else { w5 = s + (int64_t)pl.Lk - ok; w3 = s - ok + (ik - ok); }
 }
 
 }  // namespace pssbam

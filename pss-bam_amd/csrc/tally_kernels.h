@@ -37,7 +37,7 @@ constexpr int TILED_THREADS = 256;
 constexpr int TILED_WAVES = TILED_THREADS / 64;
 constexpr int TILED_MAX_N = 30;        // N+2 positions per end must fit 32 lanes
 constexpr int WIN_DWORDS = 9;          // 32 window bytes + 3 alignment bytes <= 36
-constexpr int KMER_LDS_MAX_K = 5;      // 2 * 4^5 * 4 B = 8 KiB of LDS
+constexpr int KMER_LDS_MAX_K = 4;      // 2 * 4^4 * 4 B = 2 KiB of LDS
 constexpr uint32_t STAGE_SLACK = 64;   // readable bytes behind a staging buffer
 constexpr uint32_t PAIR_LUT_BYTES = 2 * 17 * 8;
 constexpr uint32_t CODE_NONE = 32;     // sheet byte meaning "no count" (33 once the table bit is OR-ed in)
@@ -112,19 +112,14 @@ __device__ __forceinline__ bool tally_one_kmer(const TallyParams &P, const Plan 
     return true;
 }
 
-// both k-mer adds of one record; returns the stats bit (OK / FAIL) it earns
+// both k-mer adds of one record; true = an attempted add failed (fragkon's status -1)
 // (fragkon.c:164-181: both attempted, 0 only if both succeeded; :198-210 single add)
 template <bool LDS_KMER>
-__device__ __forceinline__ uint32_t tally_kmer_record(const TallyParams &P, const Plan &pl, uint32_t *lds_kmer) {
+__device__ __forceinline__ bool tally_kmer_record(const TallyParams &P, const Plan &pl, uint32_t *lds_kmer) {
     bool good = true;
     if (pl.fk5) good = tally_one_kmer<LDS_KMER>(P, pl, 0u, lds_kmer) && good;
     if (pl.fk3) good = tally_one_kmer<LDS_KMER>(P, pl, 1u, lds_kmer) && good;
-    return good ? (1u << ST_KMER_OK) : (1u << ST_KMER_FAIL);
-}
-
-__device__ __forceinline__ void flush_stats(const TallyParams &P, uint32_t *lds_stats) {
-    for (uint32_t i = threadIdx.x; i < (uint32_t)ST_USED; i += blockDim.x)
-        if (lds_stats[i]) atomicAdd(&P.counters[P.off_stats + i], (unsigned long long)lds_stats[i]);
+    return !good;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -134,35 +129,30 @@ __device__ __forceinline__ void flush_stats(const TallyParams &P, uint32_t *lds_
 template <bool LDS_TABLE>
 __global__ void __launch_bounds__(256) tally_simple(const TallyParams P) {
     extern __shared__ __attribute__((aligned(16))) uint32_t dyn_lds[];
-    __shared__ uint32_t lds_stats[ST_USED];
+    __shared__ int32_t lds_delta[ST_USED];
     const uint32_t rows = (uint32_t)P.N + 2u;
     const uint32_t tab_words = LDS_TABLE ? 2u * rows * 16u : 0u;
+    const bool do_pss = (P.tally_mask & 1u) != 0, do_kmer = (P.tally_mask & 2u) != 0;
     for (uint32_t i = threadIdx.x; i < tab_words; i += blockDim.x) dyn_lds[i] = 0u;
-    if (threadIdx.x < ST_USED) lds_stats[threadIdx.x] = 0u;
+    if (threadIdx.x < ST_USED) lds_delta[threadIdx.x] = 0;
     __syncthreads();
-
-    uint32_t my_stats[ST_USED];
-#pragma unroll
-    for (int i = 0; i < ST_USED; i++) my_stats[i] = 0u;
 
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < P.n_recs; r += stride) {
         const uint32_t o0 = P.offs[r], o1 = P.offs[r + 1];
         GlobalBytes src{P.recs + o0};
         const RecHdr h = decode_hdr(src, o1 - o0);
-        const Plan pl = make_plan(P, src, h);
-        uint32_t m = pl.st_mask;
+        Plan pl = make_plan<true, true>(P, src, h);
+        if (!do_pss) pl.pss_fwd = pl.pss_rev = false;
+        if (!do_kmer) pl.fk5 = pl.fk3 = false;
         if (pl.pss_fwd || pl.pss_rev) {
             if (LDS_TABLE) tally_pss_record(P, LdsTableRowMajor{dyn_lds, rows}, src, h, pl);
             else tally_pss_record(P, GlobalTable{P.counters, P.off_rev}, src, h, pl);
         }
-        if (pl.fk5 || pl.fk3) m |= tally_kmer_record<false>(P, pl, nullptr);
-#pragma unroll
-        for (int i = 0; i < ST_USED; i++) my_stats[i] += (m >> i) & 1u;
+        bool kfail = false;
+        if (pl.fk5 || pl.fk3) kfail = tally_kmer_record<false>(P, pl, nullptr);
+        book_events(do_pss, do_kmer, record_events(do_pss, do_kmer, pl, kfail), lds_delta);
     }
-#pragma unroll
-    for (int i = 0; i < ST_USED; i++)
-        if (my_stats[i]) atomicAdd(&lds_stats[i], my_stats[i]);
     __syncthreads();
     if (LDS_TABLE) {
         for (uint32_t i = threadIdx.x; i < tab_words; i += blockDim.x) {
@@ -173,38 +163,51 @@ __global__ void __launch_bounds__(256) tally_simple(const TallyParams P) {
             }
         }
     }
-    flush_stats(P, lds_stats);
+    flush_events(do_pss, do_kmer, P, lds_delta);
 }
 
 // ---------------------------------------------------------------------------------------
 // tally_tiled
 // ---------------------------------------------------------------------------------------
-// dynamic LDS carve-up (all 16-byte aligned):
-//   stage  : tile_bytes_cap + STAGE_SLACK      raw BAM bytes of the current tile
-//   sheet  : T * 64                            code sheet [read][end*32 + position]
-//   table  : 34 * 32 * 4                       [(cell<<1)|table][row] u32; rows 32,33 = trash bin for
-//                                              "no count" codes, so the column pass needs no branches
-//   lut    : PAIR_LUT_BYTES (padded to 16)     (strand, nibble row, ref code) -> code
-//   ctxf   : 256                               -U / -D membership flags per stored genome byte
-//   toffs  : (T + 8) * 4                       the tile's record offsets (+ next tile's geometry)
-//   kmer   : 2 * 4^K * 4   (only when K <= KMER_LDS_MAX_K and the k-mer tally is on)
+// LDS objects.  Only the staging buffer is dynamic (extern) LDS; everything the kernel touches
+// while an LDS-DMA transfer is in flight is a SEPARATE static object, so the compiler can prove
+// those accesses do not alias the DMA destination and does not fence them behind vmcnt(0):
+//   stage  (dynamic) : tile_bytes_cap + STAGE_SLACK   raw BAM bytes of the current tile
+//   sheet  : TILED_MAX_T * 64                         code sheet [read][end*32 + position]
+//   table  : 34 * 32 * 4                              [(cell<<1)|table][row] u32; rows 32,33 = trash bin
+//                                                     for "no count" codes, so the column pass has no branches
+//   lut    : PAIR_LUT_BYTES                           (strand, nibble row, ref code) -> code
+//   ctxf   : 256                                      -U / -D membership flags per stored genome byte
+//   toffs  : (TILED_MAX_T + 4) * 4, tgeo : 16         the tile's record offsets, the next tile's geometry
+//   kmer   : 2 * 4^KMER_LDS_MAX_K * 4                 (LDS_KMER variants only)
+constexpr uint32_t TILED_MAX_T = 128;
+static_assert(TILED_MAX_T * 2 == TILED_THREADS, "CODES maps one (read, end) pair to each thread");
 __host__ __device__ inline uint32_t tiled_stage_stride(uint32_t cap) { return (cap + STAGE_SLACK + 15u) & ~15u; }
-__host__ __device__ inline uint32_t tiled_lds_bytes(uint32_t T, uint32_t cap, bool kmer_lds, int K) {
-    uint32_t b = tiled_stage_stride(cap) + T * 64u + TABLE_WORDS * 4u + ((PAIR_LUT_BYTES + 15u) & ~15u) + 256u + (T + 8u) * 4u;
-    if (kmer_lds) b += 2u * (1u << (2 * K)) * 4u;
-    return b;
-}
+__host__ __device__ inline uint32_t tiled_lds_bytes(uint32_t cap) { return tiled_stage_stride(cap); }
 
 // Streams bytes [base16, base16 + nbytes) of the record block into `stage` (nbytes is a
 // multiple of 16; the tail chunk is lane-predicated so nothing beyond it is read).
+//
+// The LDS-DMA instruction is issued through inline asm on purpose.  hipcc's waitcnt pass
+// fences EVERY later LDS access behind vmcnt(0) once it has seen an LDS-DMA it cannot
+// disambiguate (no alias-scope metadata reaches it from HIP source), which would serialise
+// the transfer against the COLUMNS pass it is meant to hide behind.  The asm form is
+// invisible to that pass; ordering is ours: the kernel waits with an explicit
+// `s_waitcnt vmcnt(0)` + barrier before any lane reads `stage`, and nothing else writes
+// `stage`.  (Compiler-counted vmcnt(N) waits for its own loads only get stricter with
+// unseen younger/older operations in flight, never weaker: vmcnt retires in order.)
 __device__ __forceinline__ void stage_tile_dma(const uint8_t *recs, uint32_t base16, uint32_t nbytes, uint8_t *stage,
                                                uint32_t wave, uint32_t lane) {
     const uint32_t n_chunks = (nbytes + 1023u) >> 10;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)stage;  // LDS byte address (low half of the generic pointer)
     for (uint32_t c = wave; c < n_chunks; c += TILED_WAVES) {
         const uint32_t off = (c << 10) + (lane << 4);
         if (off < nbytes) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(recs + base16 + off),
-                                             (__attribute__((address_space(3))) void *)(stage + (c << 10)), 16, 0, 0);
+            const uint8_t *src = recs + base16 + off;
+            const uint32_t m0v = __builtin_amdgcn_readfirstlane(lds0 + (c << 10));
+            asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(m0v) : "memory");
+            // (m0 is written: gfx950 DS instructions do not read it and hipcc keeps nothing live in
+            //  it in this kernel -- checked in the ISA; naming it as a clobber is rejected as reserved)
         }
     }
 }
@@ -220,34 +223,32 @@ __device__ __attribute__((noinline)) uint32_t tally_overflow_record(const TallyP
     const TallyParams &P = *kernarg;
     GlobalBytes gsrc{P.recs + o0};
     const RecHdr gh = decode_hdr(gsrc, o1 - o0);
-    const Plan gpl = make_plan(P, gsrc, gh);
-    uint32_t m = gpl.st_mask;
+    const Plan gpl = make_plan<DO_PSS, DO_KMER>(P, gsrc, gh);
     if (DO_PSS && (gpl.pss_fwd || gpl.pss_rev)) tally_pss_record(P, LdsTableColumnMajor{table}, gsrc, gh, gpl);
-    if (DO_KMER && (gpl.fk5 || gpl.fk3)) m |= tally_kmer_record<LDS_KMER>(P, gpl, lds_kmer);
-    return m;
+    bool kfail = false;
+    if (DO_KMER && (gpl.fk5 || gpl.fk3)) kfail = tally_kmer_record<LDS_KMER>(P, gpl, lds_kmer);
+    return record_events(DO_PSS, DO_KMER, gpl, kfail);
 }
 
 // Reference windows, one per alignment end, each with STATIC byte positions:
 //   left  end (e = 0): 32 bytes from s-2      byte w <-> row w          (0,1 context; 2+i = position i)
 //   right end (e = 1): 32 bytes up to s+L+1   byte w <-> row 31-w       (31 -> row 0, 30 -> row 1, 29-i -> 2+i)
 // Read bases: left row 2+i <-> base i ; right row 2+i <-> base L-1-i, i.e. window byte w <-> base (L-30)+w.
+// The kernel body takes its LDS regions as __restrict__ pointers: after inlining, every LDS
+// access carries alias-scope metadata, which is what lets the compiler see that the code sheet,
+// the count table and the offset buffer never alias the LDS-DMA destination (`stage`) -- without
+// it every LDS access issued while a DMA transfer is in flight is fenced behind vmcnt(0) and
+// the transfer cannot overlap the COLUMNS pass.
 template <bool DO_PSS, bool DO_KMER, bool LDS_KMER>
-__global__ void __launch_bounds__(TILED_THREADS) tally_tiled(const TallyParams P) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
-    __shared__ uint32_t lds_stats[ST_USED];
-
-    // the kernel's single argument, as it lies in the kernarg segment (for the out-of-line path)
-    const TallyParams *kernarg = (const TallyParams *)__builtin_amdgcn_kernarg_segment_ptr();
-    const uint32_t T = P.reads_per_tile;
+__device__ __forceinline__ void tally_tiled_body(const TallyParams &P, const TallyParams *kernarg,
+                                                 uint8_t *__restrict__ stage, uint8_t *__restrict__ sheet,
+                                                 uint32_t *__restrict__ table, uint8_t *__restrict__ lut,
+                                                 uint8_t *__restrict__ ctxf, uint32_t *__restrict__ toffs,
+                                                 uint32_t *__restrict__ tgeo, uint32_t *__restrict__ lds_kmer,
+                                                 int32_t *__restrict__ lds_delta) {
+    const uint32_t T = P.reads_per_tile;   // <= TILED_MAX_T
     const uint32_t cap = P.tile_bytes_cap;
-    uint8_t *stage = lds_raw;
-    uint8_t *sheet = lds_raw + tiled_stage_stride(cap);
-    uint32_t *table = (uint32_t *)(sheet + T * 64u);
-    uint8_t *lut = (uint8_t *)(table + TABLE_WORDS);
-    uint8_t *ctxf = lut + ((PAIR_LUT_BYTES + 15u) & ~15u);
-    uint32_t *toffs = (uint32_t *)(ctxf + 256u);
-    uint32_t *tgeo = toffs + T + 4u;   // [0] = offs[first read of next tile], [1] = offs[one past its last]
-    uint32_t *lds_kmer = toffs + T + 8u;
+    const uint32_t ablate = P.ablate;      // diagnostics only (PSSBAM_ABLATE): 1 no COLUMNS, 2 no position loop, 4 no CODES
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u, wave = tid >> 6;
@@ -258,7 +259,7 @@ __global__ void __launch_bounds__(TILED_THREADS) tally_tiled(const TallyParams P
     for (uint32_t i = tid; i < TABLE_WORDS; i += TILED_THREADS) table[i] = 0u;
     if (LDS_KMER)
         for (uint32_t i = tid; i < 2u * (1u << (2 * P.K)); i += TILED_THREADS) lds_kmer[i] = 0u;
-    if (tid < ST_USED) lds_stats[tid] = 0u;
+    if (tid < ST_USED) lds_delta[tid] = 0;
     for (uint32_t i = tid; i < PAIR_LUT_BYTES; i += TILED_THREADS) {
         // index = strand*136 + row*8 + g ; row 0..15 = read nibble, row 16 = context position
         // (cell of a context base is the diagonal one, pss-bam.c:172-184); g = min(stored, 4)
@@ -289,10 +290,6 @@ __global__ void __launch_bounds__(TILED_THREADS) tally_tiled(const TallyParams P
             dead_w[k] = mk;
         }
     }
-
-    uint32_t my_stats[ST_USED];
-#pragma unroll
-    for (int i = 0; i < ST_USED; i++) my_stats[i] = 0u;
 
     const uint32_t n_tiles = (P.n_recs + T - 1u) / T;
     const uint32_t tstride = gridDim.x;
@@ -335,63 +332,82 @@ __global__ void __launch_bounds__(TILED_THREADS) tally_tiled(const TallyParams P
         uint32_t nxt_base16 = 0, nxt_staged = 0;
         if (next < n_tiles) geom(tgeo[0], tgeo[1], nxt_base16, nxt_staged);
 
-        // ---- CODES: lane pair per read ------------------------------------------------------
-        // (TILED_THREADS is even, so a thread keeps the same end e = tid & 1 on every pass)
-        for (uint32_t p = tid; p < 2u * T; p += TILED_THREADS) {
-            const uint32_t j = p >> 1, e = p & 1u;  // e = 0: left alignment end, 1: right end
-            const bool in_tile = j < count;
-            uint32_t o0 = 0, o1 = 0;
-            if (in_tile) { o0 = toffs[j]; o1 = toffs[j + 1]; }
-            const bool in_stage = in_tile && (o1 - cur_base16 <= cur_staged);
-            // records outside the tile / the staging window decode a harmless dummy (offset 0, length
-            // 0 -> malformed -> dead) so the lanes of a wave stay on one path
-            LdsBytes src{stage, in_stage ? o0 - cur_base16 : 0u};
-            const RecHdr h = decode_hdr_lds(src, in_stage ? o1 - o0 : 0u);
-            Plan pl = plan_head(P, src, h);
-            if (!in_stage) { pl.st_mask = 0u; pl.live = pl.pss_cand = pl.fk5 = pl.fk3 = false; }
-            // this end's reference window, issued for every candidate before the -U/-D test so the
-            // test costs no extra memory round trip
-            const bool cand = DO_PSS && pl.pss_cand;
-            uint32_t gw[WIN_DWORDS];
+        // ---- CODES, part A: everything that reads `stage` ---------------------------------------
+        // A lane pair per read (TILED_MAX_T * 2 == TILED_THREADS: one (read, end) per thread).
+        // e = 0: left alignment end, 1: right end.
+        const uint32_t j = tid >> 1, e = tid & 1u;
+        const bool lane_on = tid < 2u * T && !(ablate & 4u);
+        const bool in_tile = lane_on && j < count;
+        uint32_t o0 = 0, o1 = 0;
+        if (in_tile) { o0 = toffs[j]; o1 = toffs[j + 1]; }
+        const bool in_stage = in_tile && (o1 - cur_base16 <= cur_staged);
+        // records outside the tile / the staging window decode a harmless dummy (offset 0, length
+        // 0 -> malformed -> dead) so the lanes of a wave stay on one path
+        LdsBytes src{stage, in_stage ? o0 - cur_base16 : 0u};
+        const RecHdr h = decode_hdr_lds(src, in_stage ? o1 - o0 : 0u);
+        Plan pl = plan_head<DO_PSS, DO_KMER>(P, src, h);
+        if (!in_stage) { pl.status = RS_LIVE; pl.live = pl.pss_cand = pl.fk5 = pl.fk3 = false; }
+        // this end's reference window, issued for every candidate before the -U/-D test so the
+        // test costs no extra memory round trip
+        const bool cand = DO_PSS && pl.pss_cand;
+        uint32_t gw[WIN_DWORDS];
 #pragma unroll
-            for (int k = 0; k < WIN_DWORDS; k++) gw[k] = 0u;
-            if (cand) {
-                const uint64_t ga = pl.gbase + (uint64_t)pl.s + (e ? (uint64_t)pl.L - 30ull : (uint64_t)-2ll);
-                const uint32_t *pg = (const uint32_t *)(P.genome + (ga & ~3ull));
+        for (int k = 0; k < WIN_DWORDS; k++) gw[k] = 0u;
+        uint32_t gsh = 0u;
+        if (cand) {
+            const uint64_t ga = pl.gbase + (uint64_t)pl.s + (e ? (uint64_t)pl.L - 30ull : (uint64_t)-2ll);
+            const uint32_t *pg = (const uint32_t *)(P.genome + (ga & ~3ull));
 #pragma unroll
-                for (int k = 0; k < WIN_DWORDS; k++) gw[k] = pg[k];
-                const uint32_t gsh = (uint32_t)(ga & 3ull);
+            for (int k = 0; k < WIN_DWORDS; k++) gw[k] = pg[k];
+            gsh = (uint32_t)(ga & 3ull);
+        }
+        // read bases of this end as a nibble stream aligned with the window bytes: stream nibble
+        // b <-> read base n0 + b, n0 = -2 (left: bytes 0,1 are context, their nibbles are never
+        // used) or L-30 (right).  20 bytes from SEQ as six aligned dwords, one batch.
+        const int32_t n0 = e ? (int32_t)pl.L - 30 : -2;
+        uint32_t rr[6];
 #pragma unroll
-                for (int k = 0; k < WIN_DWORDS - 1; k++) gw[k] = __builtin_amdgcn_alignbyte(gw[k + 1], gw[k], gsh);
-            }
+        for (int k = 0; k < 6; k++) rr[k] = 0u;
+        uint32_t ssh = 0u;
+        if (cand) {
+            const uint32_t sa = src.off + (uint32_t)((int32_t)h.seq_off + (n0 >> 1));  // arithmetic shift = floor
+            const uint32_t *qs = (const uint32_t *)(stage + (sa & ~3u));
+            ssh = sa & 3u;
+#pragma unroll
+            for (int k = 0; k < 6; k++) rr[k] = qs[k];
+        }
+        uint32_t ev_over = 0u;  // events of a record handled by the out-of-line path
+        if (in_tile && !in_stage && e == 0u)
+            ev_over = tally_overflow_record<DO_PSS, DO_KMER, LDS_KMER>(kernarg, o0, o1, table, lds_kmer);
+        __syncthreads();
+
+        // every wave is done with `stage` and `toffs`: the next tile's DMA and offset loads start
+        // now and land behind the rest of CODES and the COLUMNS pass
+        if (next < n_tiles) {
+            load_offsets(next);
+            stage_tile_dma(P.recs, nxt_base16, nxt_staged, stage, wave, lane);
+            if (next + tstride < n_tiles) load_geo(next + tstride);
+            cur_base16 = nxt_base16;
+            cur_staged = nxt_staged;
+        }
+
+        // ---- CODES, part B: registers + genome + LUT only ------------------------------------------
+        {
+#pragma unroll
+            for (int k = 0; k < WIN_DWORDS - 1; k++) gw[k] = __builtin_amdgcn_alignbyte(gw[k + 1], gw[k], gsh);
             // first context base next to the alignment: left window byte 1 (s-1), right window byte 30 (s+L)
             const uint32_t own1 = e ? (gw[7] >> 16) & 0xFFu : (gw[0] >> 8) & 0xFFu;
             const uint32_t other1 = (uint32_t)__shfl_xor((int)own1, 1);
-            if (DO_PSS && in_stage) plan_finish_pss(P, CtxLds{ctxf}, pl, e ? other1 : own1, e ? own1 : other1);
-            uint32_t m = pl.st_mask;
-
+            if (DO_PSS) plan_finish_pss(CtxLds{ctxf}, pl, e ? other1 : own1, e ? own1 : other1);
             uint32_t code_w[8];
 #pragma unroll
             for (int k = 0; k < 8; k++) code_w[k] = CODE_NONE * 0x01010101u;
             // this lane's end feeds: left -> fwd table on forward reads, rev table on reverse reads
             const uint32_t tsel = e ^ (pl.rev ? 1u : 0u);
-            if (cand && (tsel ? pl.pss_rev : pl.pss_fwd)) {
-                // read bases of this end as a nibble stream aligned with the window bytes:
-                // stream nibble b <-> read base n0 + b, n0 = -2 (left: bytes 0,1 are context and
-                // their two nibbles are never used) or L-30 (right)
-                const int32_t n0 = e ? (int32_t)pl.L - 30 : -2;
-                const uint32_t sb = (uint32_t)((int32_t)h.seq_off + (n0 >> 1));  // arithmetic shift = floor
+            if (cand && (tsel ? pl.pss_rev : pl.pss_fwd) && !(ablate & 2u)) {
                 uint32_t sw[5];
-                {   // 20 bytes from sb as six aligned dwords, one batch
-                    const uint32_t sa = src.off + sb;
-                    const uint32_t ssh = sa & 3u;
-                    const uint32_t *qs = (const uint32_t *)(stage + (sa & ~3u));
-                    uint32_t rr[6];
 #pragma unroll
-                    for (int k = 0; k < 6; k++) rr[k] = qs[k];
-#pragma unroll
-                    for (int k = 0; k < 5; k++) sw[k] = __builtin_amdgcn_alignbyte(rr[k + 1], rr[k], ssh);
-                }
+                for (int k = 0; k < 5; k++) sw[k] = __builtin_amdgcn_alignbyte(rr[k + 1], rr[k], ssh);
 #pragma unroll
                 for (int k = 0; k < 5; k++)  // high nibble first -> nibble q at bits 4q
                     sw[k] = ((sw[k] & 0x0F0F0F0Fu) << 4) | ((sw[k] >> 4) & 0x0F0F0F0Fu);
@@ -412,14 +428,11 @@ __global__ void __launch_bounds__(TILED_THREADS) tally_tiled(const TallyParams P
                 // base, the LUT then yields the diagonal cell (pss-bam.c:172-184).  Left: bytes 0,1;
                 // right: bytes 30,31.
                 {
-                    const uint32_t ca = e ? 30u : 0u;  // first of the two context bytes
                     const uint32_t ga_ = min((e ? gw[7] >> 16 : gw[0]) & 0xFFu, 3u);
                     const uint32_t gb_ = min((e ? gw[7] >> 24 : gw[0] >> 8) & 0xFFu, 3u);
-                    const uint32_t two = (1u << ga_) | ((1u << gb_) << 4);  // nibbles for bytes ca, ca+1
-                    const uint32_t word = ca >> 3, sh4 = 4u * (ca & 7u);
-                    // word 0 (left) or word 3 (right), bits [sh4, sh4+8)
-                    if (word == 0u) sw[0] = (sw[0] & ~(0xFFu << sh4)) | (two << sh4);
-                    else sw[3] = (sw[3] & ~(0xFFu << sh4)) | (two << sh4);
+                    const uint32_t two = (1u << ga_) | ((1u << gb_) << 4);  // nibbles of the two context bytes
+                    if (e == 0u) sw[0] = (sw[0] & ~0xFFu) | two;                     // stream nibbles 0,1
+                    else sw[3] = (sw[3] & 0x00FFFFFFu) | (two << 24);               // stream nibbles 30,31
                 }
                 const uint8_t *lut_s = lut + (pl.rev ? 136u : 0u);
                 const uint32_t tsel4 = tsel * 0x01010101u;  // CODE_NONE | 1 is a trash row too
@@ -445,38 +458,24 @@ __global__ void __launch_bounds__(TILED_THREADS) tally_tiled(const TallyParams P
                 kmer_try = true;
                 kmer_ok = tally_one_kmer<LDS_KMER>(P, pl, e, lds_kmer);
             }
-            if (in_tile && !in_stage && e == 0u)
-                m = tally_overflow_record<DO_PSS, DO_KMER, LDS_KMER>(kernarg, o0, o1, table, lds_kmer);
-            // code sheet row of read j: bytes [e*32, e*32+32)
-            uint4 *dst = (uint4 *)(sheet + j * 64u + e * 32u);
-            dst[0] = make_uint4(code_w[0], code_w[1], code_w[2], code_w[3]);
-            dst[1] = make_uint4(code_w[4], code_w[5], code_w[6], code_w[7]);
+            if (lane_on) {  // code sheet row of read j: bytes [e*32, e*32+32)
+                uint4 *dst = (uint4 *)(sheet + j * 64u + e * 32u);
+                dst[0] = make_uint4(code_w[0], code_w[1], code_w[2], code_w[3]);
+                dst[1] = make_uint4(code_w[4], code_w[5], code_w[6], code_w[7]);
+            }
+            bool kfail = false;
             if (DO_KMER) {
-                // fragkon status of the read = AND over the adds that were attempted (both lanes)
-                const int tried = (kmer_try ? 1 : 0), good = (kmer_ok ? 1 : 0);
-                const int tried_o = __shfl_xor(tried, 1), good_o = __shfl_xor(good, 1);
-                if (e == 0u && (tried || tried_o))
-                    m |= (good && good_o) ? (1u << ST_KMER_OK) : (1u << ST_KMER_FAIL);
+                // fragkon status of the read: -1 when any attempted add failed (either lane of the pair)
+                const int bad = (kmer_try && !kmer_ok) ? 1 : 0;
+                const int bad_other = __shfl_xor(bad, 1);  // every lane takes part in the exchange
+                kfail = (bad | bad_other) != 0;
             }
-            if (e == 0u) {
-#pragma unroll
-                for (int i = 0; i < ST_USED; i++) my_stats[i] += (m >> i) & 1u;
-            }
+            if (e == 0u) book_events(DO_PSS, DO_KMER, in_stage ? record_events(DO_PSS, DO_KMER, pl, kfail) : ev_over, lds_delta);
         }
         __syncthreads();
 
-        // every wave is past CODES (the only reader of `stage` and `toffs`): start the next tile's
-        // DMA and offset loads now, they land behind the COLUMNS pass
-        if (next < n_tiles) {
-            load_offsets(next);
-            stage_tile_dma(P.recs, nxt_base16, nxt_staged, stage, wave, lane);
-            if (next + tstride < n_tiles) load_geo(next + tstride);
-            cur_base16 = nxt_base16;
-            cur_staged = nxt_staged;
-        }
-
         // ---- COLUMNS: wave-per-read, lane = (end, window byte) -----------------------------------
-        if (DO_PSS) {
+        if (DO_PSS && !(ablate & 1u)) {
             const uint32_t e = lane >> 5, b = lane & 31u;
             const uint32_t row = e ? 31u - b : b;
             const uint32_t per_wave = (count + TILED_WAVES - 1u) / TILED_WAVES;
@@ -495,9 +494,6 @@ __global__ void __launch_bounds__(TILED_THREADS) tally_tiled(const TallyParams P
         }
     }
 
-#pragma unroll
-    for (int i = 0; i < ST_USED; i++)
-        if (my_stats[i]) atomicAdd(&lds_stats[i], my_stats[i]);
     __syncthreads();
     if (DO_PSS) {
         for (uint32_t i = tid; i < 32u * 32u; i += TILED_THREADS) {  // code rows 32,33 are the trash bin
@@ -514,7 +510,23 @@ __global__ void __launch_bounds__(TILED_THREADS) tally_tiled(const TallyParams P
             if (v) atomicAdd(&P.counters[(i < nb ? P.off_k5 + i : P.off_k3 + (i - nb))], (unsigned long long)v);
         }
     }
-    flush_stats(P, lds_stats);
+    flush_events(DO_PSS, DO_KMER, P, lds_delta);
+}
+
+template <bool DO_PSS, bool DO_KMER, bool LDS_KMER>
+__global__ void __launch_bounds__(TILED_THREADS) tally_tiled(const TallyParams P) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t stage[];
+    __shared__ __attribute__((aligned(16))) uint8_t sheet[TILED_MAX_T * 64u];
+    __shared__ uint32_t table[TABLE_WORDS];
+    __shared__ __attribute__((aligned(16))) uint8_t lut[PAIR_LUT_BYTES];
+    __shared__ uint8_t ctxf[256];
+    __shared__ uint32_t toffs[TILED_MAX_T + 4u];
+    __shared__ uint32_t tgeo[4];   // [0] = offs[first read of the next tile], [1] = offs[one past its last]
+    __shared__ uint32_t lds_kmer[LDS_KMER ? 2u * (1u << (2 * KMER_LDS_MAX_K)) : 1u];
+    __shared__ int32_t lds_delta[ST_USED];
+    // the kernel's single argument, as it lies in the kernarg segment (for the out-of-line path)
+    const TallyParams *kernarg = (const TallyParams *)__builtin_amdgcn_kernarg_segment_ptr();
+    tally_tiled_body<DO_PSS, DO_KMER, LDS_KMER>(P, kernarg, stage, sheet, table, lut, ctxf, toffs, tgeo, lds_kmer, lds_delta);
 }
 
 // Upload-time genome transform: toupper() fold (init_genome stores upper case,
