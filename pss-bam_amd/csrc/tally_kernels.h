@@ -180,6 +180,12 @@ __global__ void __launch_bounds__(256) tally_simple(const TallyParams P) {
 //   ctxf   : 256                                      -U / -D membership flags per stored genome byte
 //   toffs  : (TILED_MAX_T + 4) * 4, tgeo : 16         the tile's record offsets, the next tile's geometry
 //   kmer   : 2 * 4^KMER_LDS_MAX_K * 4                 (LDS_KMER variants only)
+// Four dwords at 4-byte alignment: gfx950 global loads only need dword alignment, so this
+// compiles to ONE global_load_dwordx4 per lane.  A gather's cost in the texture addresser is per
+// wave-instruction and per distinct line touched -- nine single-dword gathers of a 36-byte
+// window cost three times what 2 x dwordx4 + 1 x dword do.
+struct __attribute__((packed, aligned(4))) Quad { uint32_t v[4]; };
+
 constexpr uint32_t TILED_MAX_T = 128;
 static_assert(TILED_MAX_T * 2 == TILED_THREADS, "CODES maps one (read, end) pair to each thread");
 __host__ __device__ inline uint32_t tiled_stage_stride(uint32_t cap) { return (cap + STAGE_SLACK + 15u) & ~15u; }
@@ -357,8 +363,10 @@ __device__ __forceinline__ void tally_tiled_body(const TallyParams &P, const Tal
         if (cand) {
             const uint64_t ga = pl.gbase + (uint64_t)pl.s + (e ? (uint64_t)pl.L - 30ull : (uint64_t)-2ll);
             const uint32_t *pg = (const uint32_t *)(P.genome + (ga & ~3ull));
+            const Quad q0 = *(const Quad *)pg, q1 = *(const Quad *)(pg + 4);
 #pragma unroll
-            for (int k = 0; k < WIN_DWORDS; k++) gw[k] = pg[k];
+            for (int k = 0; k < 4; k++) { gw[k] = q0.v[k]; gw[4 + k] = q1.v[k]; }
+            gw[8] = pg[8];
             gsh = (uint32_t)(ga & 3ull);
         }
         // read bases of this end as a nibble stream aligned with the window bytes: stream nibble
@@ -375,6 +383,23 @@ __device__ __forceinline__ void tally_tiled_body(const TallyParams &P, const Tal
             ssh = sa & 3u;
 #pragma unroll
             for (int k = 0; k < 6; k++) rr[k] = qs[k];
+        }
+        // fragkon window of this side of the alignment, fetched now so its latency overlaps the
+        // other loads: the left-end lane owns the window at s-k/2.. (5' k-mer of a forward read, 3'
+        // of a reverse read), the right-end lane the one at ..s+L+k/2 (fragkon.c:152-181)
+        const uint32_t kwhich = e ^ (pl.rev ? 1u : 0u);  // 0 = 5' table, 1 = 3' table
+        const bool kmer_try = DO_KMER && (kwhich ? pl.fk3 : pl.fk5) && !(ablate & 16u);
+        uint32_t kw[4] = {0u, 0u, 0u, 0u};
+        uint32_t ksh = 0u;
+        if (kmer_try) {
+            int64_t w5, w3;
+            kmer_windows(pl, P.K, w5, w3);
+            const uint64_t ka = pl.gbase + (uint64_t)(kwhich ? w3 : w5);
+            const uint32_t *pk = (const uint32_t *)(P.genome + (ka & ~3ull));
+            const Quad kq = *(const Quad *)pk;  // 12 window bytes at any alignment, one gather
+#pragma unroll
+            for (int k = 0; k < 4; k++) kw[k] = kq.v[k];
+            ksh = (uint32_t)(ka & 3ull);
         }
         uint32_t ev_over = 0u;  // events of a record handled by the out-of-line path
         if (in_tile && !in_stage && e == 0u)
@@ -453,10 +478,26 @@ __device__ __forceinline__ void tally_tiled_body(const TallyParams &P, const Tal
                                                ((CODE_NONE * 0x01010101u) & dead_w[4 * half + k]);
                 }
             }
-            bool kmer_try = false, kmer_ok = true;
-            if (DO_KMER && (e ? pl.fk3 : pl.fk5)) {
-                kmer_try = true;
-                kmer_ok = tally_one_kmer<LDS_KMER>(P, pl, e, lds_kmer);
+            bool kmer_ok = true;
+            if (kmer_try) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) kw[k] = __builtin_amdgcn_alignbyte(kw[k + 1], kw[k], ksh);
+                // bin = base-4 number of the k bases read left to right (kmer.c:184-214); for a
+                // reverse-strand read the window is reverse-complemented (fragkon.c:156-160)
+                uint32_t bin = 0u, bad = 0u;
+#pragma unroll
+                for (int t = 0; t < 12; t++) {
+                    if (t < P.K) {
+                        const uint32_t c = (kw[t >> 2] >> (8 * (t & 3))) & 0xFFu;
+                        bad |= c & ~3u;
+                        bin = pl.rev ? (bin | ((3u - (c & 3u)) << (2 * t))) : ((bin << 2) | (c & 3u));
+                    }
+                }
+                kmer_ok = bad == 0u;
+                if (kmer_ok && !(ablate & 8u)) {
+                    if (LDS_KMER) atomicAdd(&lds_kmer[(kwhich ? (1u << (2 * P.K)) : 0u) + bin], 1u);
+                    else atomicAdd(&P.counters[(kwhich ? P.off_k3 : P.off_k5) + bin], 1ull);
+                }
             }
             if (lane_on) {  // code sheet row of read j: bytes [e*32, e*32+32)
                 uint4 *dst = (uint4 *)(sheet + j * 64u + e * 32u);

@@ -22,7 +22,7 @@ int main(int argc, char **argv)
         fprintf(stderr, "usage: bam2sam [-r READGROUP] file.bam\n");
         return 2;
     }
-    bam_reader *rd = bam_reader_open(path, 0, 64u << 20, err, sizeof err);
+    bam_reader *rd = bam_reader_open(path, 0, 0, err, sizeof err);
     if (!rd) {
         fprintf(stderr, "bam2sam: %s\n", err);
         return 1;

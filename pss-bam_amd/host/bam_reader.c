@@ -25,6 +25,7 @@
 #include <zlib.h>
 
 #define BGZF_MAX_BLOCK 65536u
+#define UPAD 4096u /* slack behind each batch buffer (device over-reads, page alignment) */
 
 typedef struct {
     size_t coff;     /* offset of the block in the compressed slab */
@@ -41,11 +42,22 @@ struct bam_reader {
     uint8_t *cbuf;
     size_t ccap, clen, cpos; /* valid bytes [cpos, clen) */
     int file_eof;
-    /* inflated batch */
-    uint8_t *ubuf;
+    /* inflated batches: two buffers (one allocation).  The caller works on `cur` while a
+     * background thread already inflates the following batch into the other one. */
+    uint8_t *ubase;    /* the allocation: 2 * (ucap + UPAD) bytes                          */
+    uint8_t *ubuf;     /* = buffer `cur`                                                  */
+    int cur;
     size_t ucap;
-    size_t ulen;   /* valid inflated bytes            */
-    size_t upos;   /* first byte not yet handed out   */
+    size_t ulen;       /* valid inflated bytes of buffer `cur`                            */
+    size_t upos;       /* first byte of it not yet handed out                             */
+    /* background fill of the other buffer */
+    pthread_t bg_thread;
+    int bg_running;
+    int bg_rc;
+    size_t bg_ulen;    /* valid bytes the fill left in the other buffer                   */
+    const uint8_t *bg_carry;
+    size_t bg_carry_len;
+    int bg_pending;    /* a batch was handed out and its successor is being (was) prefetched */
     /* block table of the current batch */
     blk_t *blk;
     size_t n_blk, blk_cap;
@@ -57,6 +69,7 @@ struct bam_reader {
     char err[256];
     double inflate_s;
     /* worker coordination */
+    uint8_t *ubuf_fill; /* buffer the inflate workers write into */
     size_t next_blk;
     pthread_mutex_t mu;
     int worker_failed;
@@ -147,10 +160,10 @@ static void *inflate_worker(void *arg)
             inflateReset(&zs);
             zs.next_in = (Bytef *)(src + 12 + b->xlen);
             zs.avail_in = b->clen - 12 - b->xlen - 8;
-            zs.next_out = r->ubuf + b->uoff;
+            zs.next_out = r->ubuf_fill + b->uoff;
             zs.avail_out = b->isize;
             if (inflate(&zs, Z_FINISH) != Z_STREAM_END || zs.avail_out != 0 ||
-                (uint32_t)crc32(crc32(0L, Z_NULL, 0), r->ubuf + b->uoff, b->isize) != le32(src + b->clen - 8)) {
+                (uint32_t)crc32(crc32(0L, Z_NULL, 0), r->ubuf_fill + b->uoff, b->isize) != le32(src + b->clen - 8)) {
                 pthread_mutex_lock(&r->mu);
                 r->worker_failed = 1;
                 pthread_mutex_unlock(&r->mu);
@@ -161,18 +174,15 @@ static void *inflate_worker(void *arg)
     return NULL;
 }
 
-/* inflate as many whole BGZF blocks as fit behind the carried bytes; returns 0 ok / -1 error */
-static int batch_fill(bam_reader *r)
+/* Fills batch buffer `dst` with [carry bytes | as many whole inflated BGZF blocks as fit];
+ * *len_out = valid bytes.  The worker threads write into `dst` through r->ubuf_fill.
+ * Returns 0 ok / -1 error. */
+static int fill_buffer(bam_reader *r, uint8_t *dst, const uint8_t *carry, size_t carry_len, size_t *len_out)
 {
     double t0;
-    /* carry the unconsumed tail to the front */
-    if (r->upos > 0) {
-        memmove(r->ubuf, r->ubuf + r->upos, r->ulen - r->upos);
-        r->ulen -= r->upos;
-        r->upos = 0;
-    }
+    if (carry_len) memmove(dst, carry, carry_len);
     r->n_blk = 0;
-    size_t uoff = r->ulen;
+    size_t uoff = carry_len;
     for (;;) {
         if (r->clen - r->cpos < BGZF_MAX_BLOCK && !r->file_eof) {
             /* the block table refers to slab offsets: stop here if blocks are already queued */
@@ -201,10 +211,12 @@ static int batch_fill(bam_reader *r)
         uoff += isize;
         r->cpos += (size_t)bl;
     }
+    *len_out = uoff;
     if (r->n_blk == 0) return 0;
     t0 = now_s();
     r->next_blk = 0;
     r->worker_failed = 0;
+    r->ubuf_fill = dst;
     {
         int nt = r->n_threads;
         if ((size_t)nt > (r->n_blk + 7) / 8) nt = (int)((r->n_blk + 7) / 8);
@@ -221,7 +233,49 @@ static int batch_fill(bam_reader *r)
     }
     r->inflate_s += now_s() - t0;
     if (r->worker_failed) { set_err(r, "BGZF inflate / CRC check failed"); return -1; }
-    r->ulen = uoff;
+    return 0;
+}
+
+/* synchronous refill of the current buffer: keeps its unconsumed tail, appends more blocks */
+static int batch_fill(bam_reader *r)
+{
+    size_t len = 0;
+    if (fill_buffer(r, r->ubuf, r->ubuf + r->upos, r->ulen - r->upos, &len)) return -1;
+    r->ulen = len;
+    r->upos = 0;
+    return 0;
+}
+
+/* background: the batch after the current one goes into the other buffer */
+static void *bg_fill_main(void *arg)
+{
+    bam_reader *r = (bam_reader *)arg;
+    uint8_t *dst = r->ubase + (size_t)(r->cur ^ 1) * (r->ucap + UPAD);
+    r->bg_rc = fill_buffer(r, dst, r->bg_carry, r->bg_carry_len, &r->bg_ulen);
+    return NULL;
+}
+
+static void bg_start(bam_reader *r, const uint8_t *carry, size_t carry_len)
+{
+    r->bg_carry = carry;
+    r->bg_carry_len = carry_len;
+    r->bg_rc = 0;
+    r->bg_running = pthread_create(&r->bg_thread, NULL, bg_fill_main, r) == 0;
+    if (!r->bg_running) bg_fill_main(r); /* no thread: do it now */
+}
+
+/* waits for the background fill and makes its buffer the current one; 0 ok / -1 error */
+static int bg_take(bam_reader *r)
+{
+    if (r->bg_running) {
+        pthread_join(r->bg_thread, NULL);
+        r->bg_running = 0;
+    }
+    if (r->bg_rc) return -1;
+    r->cur ^= 1;
+    r->ubuf = r->ubase + (size_t)r->cur * (r->ucap + UPAD);
+    r->ulen = r->bg_ulen;
+    r->upos = 0;
     return 0;
 }
 
@@ -291,14 +345,18 @@ bam_reader *bam_reader_open(const char *path, int n_threads, size_t batch_bytes,
         n_threads = n > 32 ? 32 : (n < 1 ? 1 : (int)n);
     }
     r->n_threads = n_threads;
+    if (!batch_bytes && getenv("PSSBAM_BATCH_BYTES")) batch_bytes = (size_t)strtoull(getenv("PSSBAM_BATCH_BYTES"), NULL, 10);
     r->ucap = batch_bytes ? batch_bytes : (size_t)256 << 20;
     if (r->ucap < 4 * BGZF_MAX_BLOCK) r->ucap = 4 * BGZF_MAX_BLOCK;
     r->ccap = r->ucap / 2 + 2 * BGZF_MAX_BLOCK; /* slab of compressed input per refill */
     r->cbuf = (uint8_t *)malloc(r->ccap);
-    /* page-aligned so the caller can register it for DMA; 64 spare bytes for device over-reads */
-    if (posix_memalign((void **)&r->ubuf, 4096, r->ucap + 4096) != 0) r->ubuf = NULL;
+    /* page-aligned so the caller can register it for DMA; slack for device over-reads */
+    r->ucap = (r->ucap + 4095) & ~(size_t)4095;
+    if (posix_memalign((void **)&r->ubase, 4096, 2 * (r->ucap + UPAD)) != 0) r->ubase = NULL;
+    r->ubuf = r->ubase;
+    r->cur = 0;
     pthread_mutex_init(&r->mu, NULL);
-    if (!r->cbuf || !r->ubuf) {
+    if (!r->cbuf || !r->ubase) {
         if (err) snprintf(err, errlen, "out of memory");
         bam_reader_close(r);
         return NULL;
@@ -317,12 +375,18 @@ double bam_reader_inflate_seconds(const bam_reader *r) { return r->inflate_s; }
 
 void bam_reader_buffer(const bam_reader *r, void **base, size_t *bytes)
 {
-    *base = r->ubuf;
-    *bytes = r->ucap + 4096;
+    *base = r->ubase;
+    *bytes = 2 * (r->ucap + UPAD);
 }
 
 int64_t bam_reader_next(bam_reader *r, const uint8_t **records, const uint32_t **offsets, size_t *nbytes)
 {
+    /* the batch handed out by the previous call is finished with: switch to the one the
+     * background thread has been inflating meanwhile */
+    if (r->bg_running || r->bg_pending) {
+        r->bg_pending = 0;
+        if (bg_take(r)) return -1;
+    }
     for (;;) {
         /* index whole records in [upos, ulen) */
         size_t o = r->upos, n = 0;
@@ -344,9 +408,13 @@ int64_t bam_reader_next(bam_reader *r, const uint8_t **records, const uint32_t *
             *offsets = r->offs;
             *nbytes = o - r->upos;
             r->upos = o;
+            /* start inflating the following batch behind the caller's work on this one; the
+             * unconsumed tail (a partial record) is carried over by the fill itself */
+            bg_start(r, r->ubuf + o, r->ulen - o);
+            r->bg_pending = 1;
             return (int64_t)n;
         }
-        /* nothing whole in hand: inflate more */
+        /* nothing whole in hand: inflate more, synchronously */
         size_t have = r->ulen - r->upos;
         if (have >= 4) {
             uint32_t bs = le32(r->ubuf + r->upos);
@@ -363,9 +431,10 @@ int64_t bam_reader_next(bam_reader *r, const uint8_t **records, const uint32_t *
 void bam_reader_close(bam_reader *r)
 {
     if (!r) return;
+    if (r->bg_running) pthread_join(r->bg_thread, NULL);
     if (r->fd >= 0) close(r->fd);
     free(r->cbuf);
-    free(r->ubuf);
+    free(r->ubase);
     free(r->blk);
     free(r->offs);
     free(r->hdr.text);

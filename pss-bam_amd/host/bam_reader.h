@@ -24,7 +24,8 @@ typedef struct bam_header {
 } bam_header;
 
 /* n_threads <= 0: one per online CPU (capped at 32).  batch_bytes: size of the inflated
- * batch buffer (0 = 256 MiB).  On failure returns NULL and describes it in err. */
+ * batch buffers, two of them (0 = $PSSBAM_BATCH_BYTES or 256 MiB).  On failure returns NULL
+ * and describes it in err. */
 bam_reader *bam_reader_open(const char *path, int n_threads, size_t batch_bytes, char *err, size_t errlen);
 const bam_header *bam_reader_header(const bam_reader *r);
 

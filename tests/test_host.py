@@ -225,6 +225,10 @@ def test_bam_reader_roundtrip_through_bam2sam(host, tmp_path):
         bam = tmp_path / f"x{seed}.bam"
         tl.write_bam(bam, refs, recs, level=1, rng=np.random.default_rng(seed), block=4000)
         out = subprocess.run([str(exe), str(bam)], capture_output=True, text=True, check=True).stdout
+        # tiny batch buffers: many batches, records carried across them, background prefetch busy
+        out_small = subprocess.run([str(exe), str(bam)], capture_output=True, text=True, check=True,
+                                   env={**os.environ, "PSSBAM_BATCH_BYTES": "262144"}).stdout
+        assert out_small == out
         want = "".join(tl.sam_line(r) for r in recs)
         # BAM cannot tell "RNAME not in header" from '*': the writer maps both to refID -1
         want = want.replace("\tchrNotInHeader\t", "\t*\t")
