@@ -14,6 +14,7 @@
 #include <time.h>
 
 #include "bam_reader.h"
+#include "sam_reader.h"
 
 static double now_s(void)
 {
@@ -52,38 +53,65 @@ int run_tally(const pssbam_config *cfg, Genome *genome, const char *aln_path, in
     if (n_gpus < 1) n_gpus = 1;
     if (n_gpus > 64) n_gpus = 64;
 
-    bam_reader *rd = bam_reader_open(aln_path, 0, 0, err, sizeof err);
-    if (!rd) {
+    /* BGZF BAM, or SAM text (plain / gzip): what `samtools view FILE` accepts */
+    const int is_bam = file_is_bam(aln_path);
+    bam_reader *rd = NULL;
+    sam_reader *sd = NULL;
+    int32_t refs_sent = -1;
+    if (is_bam < 0) {
+        fprintf(stderr, "Error: Unable to open %s.\n", aln_path);
+        return -1;
+    }
+    if (is_bam) rd = bam_reader_open(aln_path, 0, 0, err, sizeof err);
+    else sd = sam_reader_open(aln_path, 0, err, sizeof err);
+    if (!rd && !sd) {
         fprintf(stderr, "Error: Unable to open %s: %s\n", aln_path, err);
         return -1;
     }
-    const bam_header *hdr = bam_reader_header(rd);
     for (int g = 0; g < n_gpus; g++) {
         pssbam_config c = *cfg;
         c.device = g;
-        if (pssbam_engine_create(&c, &eng[g]) || pssbam_engine_set_genome(eng[g], genome) ||
-            pssbam_engine_set_references(eng[g], hdr->n_ref, (const char *const *)hdr->ref_name)) {
+        if (pssbam_engine_create(&c, &eng[g]) || pssbam_engine_set_genome(eng[g], genome)) {
             fprintf(stderr, "Error: GPU engine %d: %s\n", g, pssbam_last_error());
             goto done;
         }
     }
-    bam_reader_buffer(rd, &buf_base, &buf_bytes);
-    registered = pssbam_host_register(buf_base, buf_bytes) == 0; /* best effort: pageable works too */
+    if (rd) {
+        bam_reader_buffer(rd, &buf_base, &buf_bytes);
+        registered = pssbam_host_register(buf_base, buf_bytes) == 0; /* best effort: pageable works too */
+    }
 
     for (int turn = 0;; turn++) {
         const uint8_t *recs;
         const uint32_t *offs;
         size_t nbytes;
-        int64_t n = bam_reader_next(rd, &recs, &offs, &nbytes);
+        int64_t n = rd ? bam_reader_next(rd, &recs, &offs, &nbytes) : sam_reader_next(sd, &recs, &offs, &nbytes);
         if (n < 0) {
-            fprintf(stderr, "Error: %s: %s\n", aln_path, bam_reader_error(rd));
+            fprintf(stderr, "Error: %s: %s\n", aln_path, rd ? bam_reader_error(rd) : sam_reader_error(sd));
             goto done;
         }
         if (n == 0) break;
+        /* reference names: fixed by the BAM header; for SAM text the table grows as new RNAMEs
+         * show up, so it is (re)sent whenever it changed */
+        const int32_t n_ref = rd ? bam_reader_header(rd)->n_ref : sam_reader_n_ref(sd);
+        if (n_ref != refs_sent) {
+            const char *const *names = rd ? (const char *const *)bam_reader_header(rd)->ref_name : sam_reader_ref_names(sd);
+            for (int g = 0; g < n_gpus; g++)
+                if (pssbam_engine_set_references(eng[g], n_ref, names)) {
+                    fprintf(stderr, "Error: GPU engine %d: %s\n", g, pssbam_last_error());
+                    goto done;
+                }
+            refs_sent = n_ref;
+        }
         if (pssbam_engine_submit(eng[turn % n_gpus], recs, nbytes, offs, (uint32_t)n)) {
             fprintf(stderr, "Error: GPU engine: %s\n", pssbam_last_error());
             goto done;
         }
+    }
+    if (refs_sent < 0) { /* no alignment at all: the engines still need a (possibly empty) table to finish */
+        const int32_t n_ref = rd ? bam_reader_header(rd)->n_ref : sam_reader_n_ref(sd);
+        const char *const *names = rd ? (const char *const *)bam_reader_header(rd)->ref_name : sam_reader_ref_names(sd);
+        for (int g = 0; g < n_gpus; g++) (void)pssbam_engine_set_references(eng[g], n_ref, names);
     }
     if (pssbam_reduce_counters(eng, n_gpus, 0)) {
         fprintf(stderr, "Error: counter reduce: %s\n", pssbam_last_error());
@@ -103,7 +131,8 @@ int run_tally(const pssbam_config *cfg, Genome *genome, const char *aln_path, in
         fprintf(stderr, "Error: GPU engine: %s\n", pssbam_last_error());
         goto done;
     }
-    res->inflate_s = bam_reader_inflate_seconds(rd);
+    res->inflate_s = rd ? bam_reader_inflate_seconds(rd) : 0.0;
+    if (sd) res->stats[PSSBAM_ST_PARSE_SKIP] += sam_reader_lines_skipped(sd), res->stats[PSSBAM_ST_RECORDS] += sam_reader_lines_skipped(sd);
     res->n_gpus = n_gpus;
     rc = 0;
 done:
@@ -111,6 +140,7 @@ done:
         if (eng[g]) pssbam_engine_destroy(eng[g]);
     if (registered) pssbam_host_unregister(buf_base);
     bam_reader_close(rd);
+    sam_reader_close(sd);
     res->total_s = now_s() - t0;
     if (rc) run_result_free(res);
     return rc;

@@ -16,7 +16,7 @@ typedef struct run_result {
     int n_gpus;
 } run_result;
 
-/* Streams every alignment of `aln_path` (BGZF BAM) through engines built from `cfg` on
+/* Streams every alignment of `aln_path` (BGZF BAM, or SAM text plain/gzip) through engines built from `cfg` on
  * n_gpus devices (batches dealt round-robin), sums the counter blocks onto device 0 with
  * RCCL when n_gpus > 1, and returns the tables in *res (caller frees with run_result_free).
  * Returns 0, or -1 after printing a diagnostic to stderr. */

@@ -114,3 +114,30 @@ def test_reduce_counters_single_engine_is_identity(tmp_path):
     assert L.pssbam_reduce_counters(arr, 1, 0) == 0
     assert L.pssbam_reduce_counters(arr, 1, 3) != 0      # bad root
     eng.close()
+
+
+@pytest.mark.parametrize("case", [c for c in MANIFEST["cases"]], ids=lambda c: c.get("prefix") or c["stdout"])
+def test_cli_reads_sam_text_like_the_reference_pipeline(bins, case, tmp_path):
+    """the very SAM files the reference was run on (plain, and gzipped) straight into the front
+    ends: byte-identical reports, including every -R case"""
+    ds = MANIFEST["datasets"][case["dataset"]]
+    shutil.copy(GOLD / ds["fasta"], tmp_path / ds["fasta"])
+    shutil.copy(GOLD / ds["sam"], tmp_path / ds["sam"])
+    if case["tool"] == "pss-bam":
+        o = tl.PssOpts(**case["opts"])
+        pr = subprocess.run([str(bins / "pss-bam"), "-F", ds["fasta"], "-B", ds["sam"], "-o", case["prefix"]] + o.argv(),
+                            cwd=tmp_path, capture_output=True, text=True)
+        assert pr.returncode == 0, pr.stderr
+        assert (tmp_path / case["counts"]).read_text() == (GOLD / case["counts"]).read_text()
+        assert (tmp_path / case["rates"]).read_text() == (GOLD / case["rates"]).read_text()
+    else:
+        o = tl.FkOpts(**case["opts"])
+        pr = subprocess.run([str(bins / "fragkon"), "-F", ds["fasta"], "-B", ds["sam"]] + o.argv(), cwd=tmp_path,
+                            capture_output=True, text=True)
+        assert pr.returncode == 0, pr.stderr
+        assert pr.stdout == (GOLD / case["stdout"]).read_text()
+        subprocess.run(["gzip", "-k", str(tmp_path / ds["sam"])], check=True)
+        pr = subprocess.run([str(bins / "fragkon"), "-F", ds["fasta"], "-B", ds["sam"] + ".gz"] + o.argv(), cwd=tmp_path,
+                            capture_output=True, text=True)
+        assert pr.returncode == 0, pr.stderr
+        assert pr.stdout.replace(ds["sam"] + ".gz", ds["sam"]) == (GOLD / case["stdout"]).read_text()

@@ -261,3 +261,66 @@ def test_front_end_argument_handling(host, tmp_path):
     assert pr.returncode == 1 and pr.stderr.startswith("fragkon: Program for describing kmer-based")
     pr = subprocess.run([str(pss), "-F", str(tmp_path / "nope.fa"), "-B", "x.bam", "-o", "o"], capture_output=True, text=True)
     assert pr.returncode == 1 and "Reading genome sequence from:" in pr.stderr and "Cannot open file" in pr.stderr
+
+
+def test_sam_reader_encodes_what_line2saml_accepts(host, tmp_path):
+    """SAM text -> BAM records -> text again: flag/rname/pos/mapq/cigar/seq/qual survive, RG is
+    kept, lines line2saml rejects are dropped and counted, non-canonical CIGAR text becomes '*'"""
+    L, pkg = host
+    _, refs, recs = tl.fuzz_dataset(77, 800, with_rg=True)
+    sam = tmp_path / "in.sam"
+    tl.write_sam(sam, refs, recs)
+    with open(sam, "a") as fh:
+        fh.write("short\t0\tchrA\t5\n")                                              # < 11 fields
+        fh.write("lenmis\t0\tchrA\t5\t30\t3M\t*\t0\t0\tACG\tII\n")                 # SEQ/QUAL mismatch
+        fh.write("noncanon\t0\tchrA\t5\t30\t03M\t*\t0\t0\tACG\tIII\n")             # "03M" never equals "%dM"
+        fh.write("lower\t16\tchrNew\t7\t300\t3M\t*\t0\t0\tacn\tIII\tXX:i:1\tRG:Z:g9\n")
+    L.sam_reader_open.restype = C.c_void_p
+    L.sam_reader_open.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
+    L.sam_reader_next.restype = C.c_int64
+    L.sam_reader_next.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    L.sam_reader_n_ref.argtypes = [C.c_void_p]
+    L.sam_reader_ref_names.restype = C.POINTER(C.c_char_p)
+    L.sam_reader_ref_names.argtypes = [C.c_void_p]
+    L.sam_reader_lines_skipped.restype = C.c_uint64
+    L.sam_reader_lines_skipped.argtypes = [C.c_void_p]
+    L.sam_reader_close.argtypes = [C.c_void_p]
+
+    class Hdr(C.Structure):
+        _fields_ = [("text", C.c_char_p), ("l_text", C.c_uint32), ("n_ref", C.c_int32), ("ref_name", C.POINTER(C.c_char_p)),
+                    ("ref_len", C.c_void_p)]
+    L.bam_record_to_sam.restype = C.c_long
+    L.bam_record_to_sam.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(Hdr), C.c_char_p, C.c_size_t]
+    err = C.create_string_buffer(256)
+    rd = L.sam_reader_open(str(sam).encode(), 1 << 20, err, 256)
+    assert rd, err.value
+    lines = []
+    out = C.create_string_buffer(1 << 16)
+    while True:
+        recs_p, offs_p, nb = C.c_void_p(), C.c_void_p(), C.c_size_t()
+        n = L.sam_reader_next(rd, C.byref(recs_p), C.byref(offs_p), C.byref(nb))
+        assert n >= 0
+        if n == 0:
+            break
+        offs = np.ctypeslib.as_array(C.cast(offs_p, C.POINTER(C.c_uint32)), shape=(n + 1,)).copy()
+        hdr = Hdr(None, 0, L.sam_reader_n_ref(rd), L.sam_reader_ref_names(rd), None)
+        for i in range(n):
+            w = L.bam_record_to_sam(recs_p.value + int(offs[i]), int(offs[i + 1] - offs[i]), C.byref(hdr), out, 1 << 16)
+            assert w > 0
+            lines.append(out.value.decode())
+    assert L.sam_reader_lines_skipped(rd) == 2 + sum(1 for r in recs if len(r.seq) != len(r.qual))
+    L.sam_reader_close(rd)
+    kept = [r for r in recs if len(r.seq) == len(r.qual)]
+    assert len(lines) == len(kept) + 2
+    for r, ln in zip(kept, lines):
+        f = ln.rstrip("\n").split("\t")
+        assert (f[0], int(f[1]), f[2], int(f[3]), int(f[4]), f[5]) == (r.qname, r.flag, r.rname, r.pos, r.mapq, r.cigar_str())
+        want_seq = "*" if r.seq == "*" else "".join(c if c in "=ACMGRSVTWYHKDBN" else "N" for c in r.seq.upper())
+        assert f[9] == want_seq and f[10] == r.qual
+        assert int(f[8]) == (r.tlen if r.flag & 1 else 0)
+        rg = [t for t in r.tags if t[0] == "RG"]
+        assert f[11:] == ([f"RG:Z:{rg[0][2]}"] if rg else [])
+    f = lines[-2].split("\t")
+    assert f[0] == "noncanon" and f[5] == "*"
+    f = lines[-1].rstrip("\n").split("\t")
+    assert f[0] == "lower" and f[2] == "chrNew" and f[4] == "255" and f[9] == "ACN" and f[11:] == ["RG:Z:g9"]
