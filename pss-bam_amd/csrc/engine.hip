@@ -431,7 +431,9 @@ static int launch_tally(pssbam_engine *e, const uint8_t *d_recs, uint64_t nbytes
         const uint64_t avg = std::max<uint64_t>(40, nbytes / n_records);
         uint32_t T = avg * 128 <= 40 * 1024 ? 128u : 64u;
         if (e->env_tile_reads > 0) T = std::min<uint32_t>(TILED_MAX_T, (uint32_t)(e->env_tile_reads + 15) / 16 * 16);
-        uint64_t cap64 = (uint64_t)T * avg + (uint64_t)T * avg / 16 + 512;
+        // staging window: mean tile size + 3 % + 512 B; three workgroups (incl. the static LDS
+        // tables, + 2 KiB k-mer bins) must fit the CU's 160 KiB at 150-bp records
+        uint64_t cap64 = (uint64_t)T * avg + (uint64_t)T * avg / 32 + 512;
         cap64 = std::min<uint64_t>(cap64, 64 * 1024);
         if (e->env_tile_cap > 0) cap64 = (uint64_t)e->env_tile_cap;
         P.reads_per_tile = T;
