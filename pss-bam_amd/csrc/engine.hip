@@ -74,18 +74,19 @@ struct pssbam_engine {
     bool has_rg = false;
     int device = 0;
     int n_cu = 0;
+    uint32_t lds_per_cu = 160u * 1024u;
     hipStream_t stream = nullptr, copy_stream = nullptr;
     bool own_stream = false;
 
     // genome
     uint8_t *d_genome = nullptr;
     uint64_t genome_bytes = 0;
-    uint64_t *d_contig_start = nullptr;
-    uint32_t *d_contig_len = nullptr;
+    std::vector<uint64_t> contig_start;  // per sorted contig
+    std::vector<uint32_t> contig_len;
     std::vector<std::string> contig_ids;  // sorted by strcmp, like Genome.seqs
     int32_t star_contig = -1;
     // references
-    int32_t *d_ref_map = nullptr;
+    uint4 *d_ref_info = nullptr;  // n_ref + 1 entries (last = RNAME "*")
     int32_t n_ref = 0;
     bool have_refs = false;
     // -R
@@ -166,6 +167,7 @@ extern "C" int pssbam_engine_create(const pssbam_config *cfg, pssbam_engine **ou
     hipDeviceProp_t pr;
     HIP_TRY(hipGetDeviceProperties(&pr, dev));
     e->n_cu = pr.multiProcessorCount;
+    if (pr.maxSharedMemoryPerMultiProcessor > 0) e->lds_per_cu = (uint32_t)pr.maxSharedMemoryPerMultiProcessor;
     HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
     e->own_stream = true;
@@ -214,9 +216,7 @@ extern "C" void pssbam_engine_destroy(pssbam_engine *e) {
     if (e->t_begin) (void)hipEventDestroy(e->t_begin);
     if (e->t_end) (void)hipEventDestroy(e->t_end);
     if (e->d_genome) (void)hipFree(e->d_genome);
-    if (e->d_contig_start) (void)hipFree(e->d_contig_start);
-    if (e->d_contig_len) (void)hipFree(e->d_contig_len);
-    if (e->d_ref_map) (void)hipFree(e->d_ref_map);
+    if (e->d_ref_info) (void)hipFree(e->d_ref_info);
     if (e->d_rg) (void)hipFree(e->d_rg);
     if (e->d_counters_own) (void)hipFree(e->d_counters_own);
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
@@ -261,8 +261,6 @@ extern "C" int pssbam_engine_set_genome_arrays(pssbam_engine *e, size_t n, const
         total += ((uint64_t)len[k] + CONTIG_PAD + CONTIG_ALIGN - 1) / CONTIG_ALIGN * CONTIG_ALIGN;
     }
     if (e->d_genome) { HIP_TRY(hipFree(e->d_genome)); e->d_genome = nullptr; }
-    if (e->d_contig_start) { HIP_TRY(hipFree(e->d_contig_start)); e->d_contig_start = nullptr; }
-    if (e->d_contig_len) { HIP_TRY(hipFree(e->d_contig_len)); e->d_contig_len = nullptr; }
     HIP_TRY(hipMalloc(&e->d_genome, total));
     // padding = raw NUL, like the terminator the reference finds at index len (fragkon.c odd-k
     // windows); the encode pass below turns it into the stored form of NUL ("not a base")
@@ -275,10 +273,8 @@ extern "C" int pssbam_engine_set_genome_arrays(pssbam_engine *e, size_t n, const
     // raw bytes (and NUL padding) are in place: one pass folds case and applies enc_byte to all
     hipLaunchKernelGGL(encode_genome_kernel, dim3(4096), dim3(256), 0, e->stream, e->d_genome, total / 16);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMalloc(&e->d_contig_start, (n + 1) * sizeof(uint64_t)));
-    HIP_TRY(hipMalloc(&e->d_contig_len, (n + 1) * sizeof(uint32_t)));
-    HIP_TRY(hipMemcpyAsync(e->d_contig_start, start.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(hipMemcpyAsync(e->d_contig_len, len.data(), (n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+    e->contig_start.assign(start.begin(), start.begin() + n);
+    e->contig_len.assign(len.begin(), len.begin() + n);
     HIP_TRY(hipStreamSynchronize(e->stream));
     e->genome_bytes = total;
     e->contig_ids.clear();
@@ -310,21 +306,28 @@ extern "C" int pssbam_engine_set_references(pssbam_engine *e, int32_t n_ref, con
     if (!e || n_ref < 0 || (n_ref && !names)) return fail(PSSBAM_EINVAL, "bad argument");
     if (!e->d_genome) return fail(PSSBAM_ESTATE, "set_genome must precede set_references");
     HIP_TRY(hipSetDevice(e->device));
-    std::vector<int32_t> map((size_t)n_ref + 1, -1);
+    // ref_info[i] = {gbase lo, gbase hi, length, found}; entry n_ref answers RNAME "*" (refID -1)
+    std::vector<uint4> info((size_t)n_ref + 1, make_uint4(0, 0, 0, 0));
+    auto fill = [&](size_t slot, int32_t contig) {
+        if (contig < 0) return;
+        const uint64_t gb = e->contig_start[(size_t)contig];
+        info[slot] = make_uint4((uint32_t)gb, (uint32_t)(gb >> 32), e->contig_len[(size_t)contig], 1u);
+    };
     for (int32_t i = 0; i < n_ref; i++) {
         // bsearch with strcmp over the sorted ids == find_seq (fasta-genome-io.c:202-213)
         size_t lo = 0, hi = e->contig_ids.size();
         while (lo < hi) {
             const size_t mid = (lo + hi) / 2;
             const int c = strcmp(names[i], e->contig_ids[mid].c_str());
-            if (c == 0) { map[i] = (int32_t)mid; break; }
+            if (c == 0) { fill((size_t)i, (int32_t)mid); break; }
             if (c < 0) hi = mid; else lo = mid + 1;
         }
     }
+    fill((size_t)n_ref, e->star_contig);
     HIP_TRY(hipStreamSynchronize(e->stream));
-    if (e->d_ref_map) { HIP_TRY(hipFree(e->d_ref_map)); e->d_ref_map = nullptr; }
-    HIP_TRY(hipMalloc(&e->d_ref_map, ((size_t)n_ref + 1) * sizeof(int32_t)));
-    HIP_TRY(hipMemcpy(e->d_ref_map, map.data(), ((size_t)n_ref + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (e->d_ref_info) { HIP_TRY(hipFree(e->d_ref_info)); e->d_ref_info = nullptr; }
+    HIP_TRY(hipMalloc(&e->d_ref_info, ((size_t)n_ref + 1) * sizeof(uint4)));
+    HIP_TRY(hipMemcpy(e->d_ref_info, info.data(), ((size_t)n_ref + 1) * sizeof(uint4), hipMemcpyHostToDevice));
     e->n_ref = n_ref;
     e->have_refs = true;
     return PSSBAM_OK;
@@ -358,8 +361,20 @@ static int resolve_launch_events(pssbam_engine *e) {
     return PSSBAM_OK;
 }
 
+// Fits the dynamic staging window to the kernel's static LDS so that `want_wgs` workgroups
+// share one CU's LDS (160 KiB on gfx950) whenever the tile still fits; returns the occupancy
+// the runtime reports for the final size.
 template <class K>
-static int prep_kernel(K kernel, uint32_t lds_bytes, int *occ) {
+static int prep_kernel(K kernel, uint32_t lds_per_cu, uint32_t min_cap, uint32_t want_wgs, uint32_t *cap_io, int *occ) {
+    hipFuncAttributes fa;
+    HIP_TRY(hipFuncGetAttributes(&fa, (const void *)kernel));
+    const uint32_t stat = (uint32_t)fa.sharedSizeBytes;
+    const uint32_t per_wg = lds_per_cu / want_wgs;
+    if (per_wg > stat + STAGE_SLACK + 1024u) {
+        const uint32_t room = ((per_wg - stat - STAGE_SLACK - 256u) / 1024u) * 1024u;  // 256 B: allocation granule slop
+        if (room >= min_cap && room < *cap_io) *cap_io = room;
+    }
+    const uint32_t lds_bytes = tiled_lds_bytes(*cap_io);
     HIP_TRY(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(occ, kernel, TILED_THREADS, lds_bytes));
     if (*occ < 1) return fail(PSSBAM_EHIP, "kernel does not fit a CU with %u bytes of LDS", lds_bytes);
@@ -376,11 +391,8 @@ static int launch_tally(pssbam_engine *e, const uint8_t *d_recs, uint64_t nbytes
     P.n_recs = n_records;
     P.tally_mask = c.tally_mask;
     P.genome = e->d_genome;
-    P.contig_start = e->d_contig_start;
-    P.contig_len = e->d_contig_len;
-    P.ref_map = e->d_ref_map;
+    P.ref_info = e->d_ref_info;
     P.n_ref = e->n_ref;
-    P.star_contig = e->star_contig;
     const bool do_pss = (c.tally_mask & PSSBAM_TALLY_PSS) != 0, do_kmer = (c.tally_mask & PSSBAM_TALLY_KMER) != 0;
     if (do_pss) {
         P.N = c.pss.region_len;
@@ -440,16 +452,20 @@ static int launch_tally(pssbam_engine *e, const uint8_t *d_recs, uint64_t nbytes
         P.ablate = (uint32_t)env_int("PSSBAM_ABLATE");
         P.tile_bytes_cap = (uint32_t)((cap64 + 1023) & ~1023ull);
         const bool kmer_lds = do_kmer && c.kmer.klen <= KMER_LDS_MAX_K;
-        const uint32_t lds = tiled_lds_bytes(P.tile_bytes_cap);
         const uint32_t n_tiles = (n_records + T - 1) / T;
+        // smallest window that still holds a mean tile (+16 B of alignment): below it most tiles
+        // would spill to the slow path, so the occupancy target is dropped instead
+        const uint32_t min_cap = (uint32_t)(((uint64_t)T * avg + 16 + 1023) & ~1023ull);
         int occ = 0, rc = PSSBAM_OK;
         const int mult = e->env_grid_mult > 0 ? e->env_grid_mult : 1;
 #define LAUNCH_TILED(PSS, KM, LK)                                                                  \
     do {                                                                                           \
-        rc = prep_kernel(tally_tiled<PSS, KM, LK>, lds, &occ);                                     \
+        uint32_t cap = P.tile_bytes_cap;                                                           \
+        rc = prep_kernel(tally_tiled<PSS, KM, LK>, e->lds_per_cu, min_cap, 3u, &cap, &occ);        \
         if (rc == PSSBAM_OK) {                                                                     \
+            P.tile_bytes_cap = cap;                                                                \
             const uint32_t grid = (uint32_t)std::min<uint64_t>(n_tiles, (uint64_t)e->n_cu * occ * mult); \
-            hipLaunchKernelGGL((tally_tiled<PSS, KM, LK>), dim3(grid), dim3(TILED_THREADS), lds, e->stream, P); \
+            hipLaunchKernelGGL((tally_tiled<PSS, KM, LK>), dim3(grid), dim3(TILED_THREADS), tiled_lds_bytes(cap), e->stream, P); \
         }                                                                                          \
     } while (0)
         if (do_pss && do_kmer) { if (kmer_lds) LAUNCH_TILED(true, true, true); else LAUNCH_TILED(true, true, false); }

@@ -32,11 +32,11 @@ struct TallyParams {
     uint32_t n_recs;
     uint32_t tally_mask;          // PSSBAM_TALLY_*
     const uint8_t *genome;        // all contigs, 1 stored byte/base (enc_byte), padded between
-    const uint64_t *contig_start; // per genome contig (sorted-id order), one spare entry
-    const uint32_t *contig_len;   // contigs are < 4 Gi bases (the reference caps them at 536870911)
-    const int32_t *ref_map;       // BAM refID -> genome contig, -1 = find_seq fails
+    // BAM refID -> where its contig lies, resolved once per header by find_seq semantics:
+    // ref_info[refID] = {gbase lo, gbase hi, contig length, found ? 1 : 0}; entry n_ref is the
+    // one for RNAME "*" (refID -1; found only if a contig is literally named "*")
+    const uint4 *ref_info;
     int32_t n_ref;
-    int32_t star_contig;          // contig literally named "*" (refID -1), normally -1
     // pss-bam options (pss-bam.c:12-18)
     int32_t N;
     uint32_t pss_min_mq;
@@ -281,8 +281,24 @@ struct Plan {
 // Text-equivalence + contig lookup + the filters of the enabled tool(s), everything that can be
 // decided from the record alone.  No genome access.  Straight-line predicated code in 32-bit
 // arithmetic (the lanes of a wave hold different records; early returns would only serialise).
-template <bool DO_PSS, bool DO_KMER, class Src>
-__device__ __forceinline__ Plan plan_head(const TallyParams &P, const Src &src, const RecHdr &h) {
+// reference-table providers for plan_head
+struct RefsGlobal {  // straight from device memory
+    const uint4 *t;
+    __device__ __forceinline__ uint4 get(uint32_t i) const { return t[i]; }
+};
+struct RefsLdsCached {  // first `n_cached` entries (and the "*" entry, kept at index n_cached) in LDS
+    const uint4 *lds;
+    const uint4 *glob;
+    uint32_t n_cached, n_ref;
+    __device__ __forceinline__ uint4 get(uint32_t i) const {
+        if (i < n_cached) return lds[i];
+        if (i == n_ref) return lds[n_cached];
+        return glob[i];
+    }
+};
+
+template <bool DO_PSS, bool DO_KMER, class Src, class Refs>
+__device__ __forceinline__ Plan plan_head(const TallyParams &P, const Src &src, const RecHdr &h, const Refs &refs) {
     Plan pl;
     pl.pss_fwd = pl.pss_rev = false;
     pl.flag = h.flag;
@@ -295,13 +311,13 @@ __device__ __forceinline__ Plan plan_head(const TallyParams &P, const Src &src, 
     const uint32_t q0 = (h.well_formed && h.l_seq) ? src.u8(h.qual_off) : 0xFFu;
     const bool parse_skip = !h.well_formed || (q0 == 0xFFu && l_text != 1u);
 
-    // find_seq(genome, RNAME)  (pss-bam.c:393-396, fragkon.c:124-127); tables have one spare entry
+    // find_seq(genome, RNAME)  (pss-bam.c:393-396, fragkon.c:124-127), pre-resolved per refID
     const bool rid_ok = (uint32_t)h.ref_id < (uint32_t)P.n_ref;
-    const int32_t mapped = P.ref_map[rid_ok ? h.ref_id : 0];
-    const int32_t contig = rid_ok ? mapped : (h.ref_id == -1 ? P.star_contig : -1);
-    const uint32_t cidx = contig >= 0 ? (uint32_t)contig : 0u;
-    const uint32_t glen = P.contig_len[cidx];
-    pl.gbase = P.contig_start[cidx];
+    const uint4 ri = refs.get(rid_ok ? (uint32_t)h.ref_id : (uint32_t)P.n_ref);
+    const bool found = ri.w != 0u && (rid_ok || h.ref_id == -1);
+    const uint32_t glen = ri.z;
+    pl.gbase = ((uint64_t)ri.y << 32) | ri.x;
+    const int32_t contig = found ? 0 : -1;
     pl.status = rg_drop ? RS_RG_DROPPED : parse_skip ? RS_PARSE_SKIP : contig < 0 ? RS_NO_CONTIG : RS_LIVE;
     const bool live = pl.status == RS_LIVE;
     pl.live = live;
@@ -418,7 +434,7 @@ __device__ __forceinline__ void flush_events(bool DO_PSS, bool DO_KMER, const Ta
 // both steps with the two context bytes fetched from global memory (lane-per-read kernels)
 template <bool DO_PSS, bool DO_KMER, class Src>
 __device__ Plan make_plan(const TallyParams &P, const Src &src, const RecHdr &h) {
-    Plan pl = plan_head<DO_PSS, DO_KMER>(P, src, h);
+    Plan pl = plan_head<DO_PSS, DO_KMER>(P, src, h, RefsGlobal{P.ref_info});
     if (DO_PSS) {
         uint32_t l1 = 0, r1 = 0;
         if (pl.pss_cand) {

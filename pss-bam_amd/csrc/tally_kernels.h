@@ -42,6 +42,7 @@ constexpr uint32_t STAGE_SLACK = 64;   // readable bytes behind a staging buffer
 constexpr uint32_t PAIR_LUT_BYTES = 2 * 17 * 8;
 constexpr uint32_t CODE_NONE = 32;     // sheet byte meaning "no count" (33 once the table bit is OR-ed in)
 constexpr uint32_t TABLE_WORDS = 34 * 32;
+constexpr uint32_t REF_LDS_ENTRIES = 64;   // BAM references whose contig info is cached in LDS (+1 for "*")
 
 // ---------------------------------------------------------------------------------------
 // per-read tally, lane-per-read form (tally_simple, and tile-overflow records)
@@ -180,6 +181,7 @@ __global__ void __launch_bounds__(256) tally_simple(const TallyParams P) {
 //   ctxf   : 256                                      -U / -D membership flags per stored genome byte
 //   toffs  : (TILED_MAX_T + 4) * 4, tgeo : 16         the tile's record offsets, the next tile's geometry
 //   kmer   : 2 * 4^KMER_LDS_MAX_K * 4                 (LDS_KMER variants only)
+//   refs   : (REF_LDS_ENTRIES + 1) * 16               contig info of the first BAM references
 // Four dwords at 4-byte alignment: gfx950 global loads only need dword alignment, so this
 // compiles to ONE global_load_dwordx4 per lane.  A gather's cost in the texture addresser is per
 // wave-instruction and per distinct line touched -- nine single-dword gathers of a 36-byte
@@ -251,7 +253,7 @@ __device__ __forceinline__ void tally_tiled_body(const TallyParams &P, const Tal
                                                  uint32_t *__restrict__ table, uint8_t *__restrict__ lut,
                                                  uint8_t *__restrict__ ctxf, uint32_t *__restrict__ toffs,
                                                  uint32_t *__restrict__ tgeo, uint32_t *__restrict__ lds_kmer,
-                                                 int32_t *__restrict__ lds_delta) {
+                                                 int32_t *__restrict__ lds_delta, uint4 *__restrict__ refs_lds) {
     const uint32_t T = P.reads_per_tile;   // <= TILED_MAX_T
     const uint32_t cap = P.tile_bytes_cap;
     const uint32_t ablate = P.ablate;      // diagnostics only (PSSBAM_ABLATE): 1 no COLUMNS, 2 no position loop, 4 no CODES
@@ -280,6 +282,10 @@ __device__ __forceinline__ void tally_tiled_body(const TallyParams &P, const Tal
     }
 
     if (tid < 256u) ctxf[tid] = (uint8_t)((in_set(P.up_mask, tid) ? 1u : 0u) | (in_set(P.down_mask, tid) ? 2u : 0u));
+    // contig info of the first BAM references (all of them for a human-sized header) + the "*" entry
+    const uint32_t n_ref_cached = min((uint32_t)P.n_ref, REF_LDS_ENTRIES);
+    if (tid < n_ref_cached) refs_lds[tid] = P.ref_info[tid];
+    if (tid == n_ref_cached) refs_lds[tid] = P.ref_info[P.n_ref];
     // bytes of this lane's code-sheet row that lie outside the N+2 live rows stay CODE_NONE:
     // left end (row = byte) bytes >= n_pos, right end (row = 31 - byte) bytes <= 31 - n_pos
     uint32_t dead_w[8];
@@ -351,7 +357,7 @@ __device__ __forceinline__ void tally_tiled_body(const TallyParams &P, const Tal
         // 0 -> malformed -> dead) so the lanes of a wave stay on one path
         LdsBytes src{stage, in_stage ? o0 - cur_base16 : 0u};
         const RecHdr h = decode_hdr_lds(src, in_stage ? o1 - o0 : 0u);
-        Plan pl = plan_head<DO_PSS, DO_KMER>(P, src, h);
+        Plan pl = plan_head<DO_PSS, DO_KMER>(P, src, h, RefsLdsCached{refs_lds, P.ref_info, n_ref_cached, (uint32_t)P.n_ref});
         if (!in_stage) { pl.status = RS_LIVE; pl.live = pl.pss_cand = pl.fk5 = pl.fk3 = false; }
         // this end's reference window, issued for every candidate before the -U/-D test so the
         // test costs no extra memory round trip
@@ -565,9 +571,10 @@ __global__ void __launch_bounds__(TILED_THREADS) tally_tiled(const TallyParams P
     __shared__ uint32_t tgeo[4];   // [0] = offs[first read of the next tile], [1] = offs[one past its last]
     __shared__ uint32_t lds_kmer[LDS_KMER ? 2u * (1u << (2 * KMER_LDS_MAX_K)) : 1u];
     __shared__ int32_t lds_delta[ST_USED];
+    __shared__ uint4 refs_lds[REF_LDS_ENTRIES + 1];
     // the kernel's single argument, as it lies in the kernarg segment (for the out-of-line path)
     const TallyParams *kernarg = (const TallyParams *)__builtin_amdgcn_kernarg_segment_ptr();
-    tally_tiled_body<DO_PSS, DO_KMER, LDS_KMER>(P, kernarg, stage, sheet, table, lut, ctxf, toffs, tgeo, lds_kmer, lds_delta);
+    tally_tiled_body<DO_PSS, DO_KMER, LDS_KMER>(P, kernarg, stage, sheet, table, lut, ctxf, toffs, tgeo, lds_kmer, lds_delta, refs_lds);
 }
 
 // Upload-time genome transform: toupper() fold (init_genome stores upper case,
