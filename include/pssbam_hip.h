@@ -158,6 +158,11 @@ int pssbam_engine_counters_device(pssbam_engine *e, void **d_counters, size_t *n
  * counts are carried over.  NULL returns to the engine's own block. */
 int pssbam_engine_bind_counters(pssbam_engine *e, void *d_counters, size_t n_u64);
 
+/* genome-kmer-count (/root/reference/genome-kmer-count.c:56-79) on the uploaded genome: counts
+ * every k-mer start of every contig (windows touching a non-ACGT base are not counted), k in
+ * 1..12.  counts[4^k] in the same bin order as the fragkon tables.  Needs set_genome only. */
+int pssbam_engine_genome_kmer_count(pssbam_engine *e, int klen, uint64_t *counts);
+
 /* Node-level sum for one process driving several GPUs (one engine per device): adds the
  * counter blocks of engines[1..n-1] into engines[root] with ONE RCCL ncclReduce(sum,
  * uint64) per device inside a group call over xGMI (communicators from ncclCommInitAll,

@@ -658,3 +658,21 @@ int orc_fk_write(FILE *out, const char *fasta_fn, const char *bam_fn, int klen, 
     }
     return 0;
 }
+
+/* ================================================================================== */
+/* genome-kmer-count                                                                   */
+/* ================================================================================== */
+
+static int gkc_at(const void *ctx, long i) { return ((const unsigned char *)ctx)[i]; }
+
+/* count_kmers, genome-kmer-count.c:69-79: add_to_ksp at every start i < len - k + 1 */
+int orc_genome_kmer_count(const orc_genome *g, int klen, unsigned int *counts)
+{
+    if (klen < 1 || klen > 14) return -2;
+    for (size_t c = 0; c < g->n; c++) {
+        const orc_contig *s = &g->contigs[c];
+        if (s->len < (size_t)klen) continue;
+        for (size_t i = 0; i + (size_t)klen <= s->len; i++) (void)kmer_add(counts, klen, gkc_at, s->seq + i);
+    }
+    return 0;
+}

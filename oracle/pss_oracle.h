@@ -101,6 +101,11 @@ int orc_fk_process(const orc_genome *g, const orc_fk_params *p, const orc_aln *a
 int orc_fk_write(FILE *out, const char *fasta_fn, const char *bam_fn, int klen,
                  const unsigned int *k5, const unsigned int *k3);
 
+/* ---- genome-kmer-count (genome-kmer-count.c:56-79) ---------------------------------- */
+/* counts[4^klen]: every k-mer start 0..len-k of every contig, same bins / saturation as fragkon.
+ * Contigs shorter than k contribute nothing (the reference's loop bound underflows there). */
+int orc_genome_kmer_count(const orc_genome *g, int klen, unsigned int *counts);
+
 /* ---- SAM text (sam-parse.c:10-91) -------------------------------------------------- */
 /* Parses one line into *a using `scratch` (>= 3*(strlen(line)+1) bytes).
  * Returns 0 ok / 1 "problem" exactly where line2saml does.                           */

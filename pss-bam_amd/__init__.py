@@ -34,7 +34,7 @@ HIP_SYMBOLS = [
     "pssbam_engine_set_stream", "pssbam_engine_set_genome", "pssbam_engine_set_genome_arrays",
     "pssbam_engine_set_references", "pssbam_engine_submit", "pssbam_engine_submit_device", "pssbam_engine_sync",
     "pssbam_engine_finish", "pssbam_engine_reset", "pssbam_engine_counters_device", "pssbam_engine_bind_counters",
-    "pssbam_reduce_counters", "pssbam_host_register", "pssbam_host_unregister", "pssbam_engine_timer_begin",
+    "pssbam_reduce_counters", "pssbam_engine_genome_kmer_count", "pssbam_host_register", "pssbam_host_unregister", "pssbam_engine_timer_begin",
     "pssbam_engine_timer_end", "pssbam_engine_kernel_time", "pssbam_index_records",
 ]
 
@@ -92,6 +92,7 @@ def hip_lib() -> C.CDLL:
     L.pssbam_engine_reset.argtypes = [C.c_void_p]
     L.pssbam_engine_counters_device.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     L.pssbam_engine_bind_counters.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.pssbam_engine_genome_kmer_count.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.pssbam_engine_timer_begin.argtypes = [C.c_void_p]
     L.pssbam_engine_timer_end.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     L.pssbam_engine_kernel_time.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]
@@ -246,6 +247,11 @@ class Engine:
         nb = 4 ** self.klen if self.has_kmer else 0
         return {"fwd": 0, "rev": rows * 16, "k5": 2 * rows * 16, "k3": 2 * rows * 16 + nb,
                 "stats": 2 * rows * 16 + 2 * nb, "rows": rows, "bins": nb}
+
+    def genome_kmer_count(self, klen: int) -> np.ndarray:
+        out = np.zeros(4 ** klen, dtype=np.uint64)
+        _chk(self._L.pssbam_engine_genome_kmer_count(self._h, klen, out.ctypes.data))
+        return out
 
     def timer_begin(self):
         _chk(self._L.pssbam_engine_timer_begin(self._h))

@@ -107,7 +107,7 @@ struct pssbam_engine {
     double kernel_ms = 0.0;
     uint64_t kernel_launches = 0;
     // tuning overrides (environment, for experiments)
-    int env_tile_reads = 0, env_tile_cap = 0, env_grid_mult = 0, env_simple_blocks = 0;
+    int env_tile_reads = 0, env_tile_cap = 0, env_grid_mult = 0, env_simple_blocks = 0, env_grid_wgs = 0, env_want_wgs = 0;
 };
 
 static void ctx_mask(const char *set, uint32_t (&m)[8]) {
@@ -196,6 +196,8 @@ extern "C" int pssbam_engine_create(const pssbam_config *cfg, pssbam_engine **ou
     e->env_tile_cap = env_int("PSSBAM_TILE_CAP");
     e->env_grid_mult = env_int("PSSBAM_GRID_MULT");
     e->env_simple_blocks = env_int("PSSBAM_SIMPLE_BLOCKS");
+    e->env_grid_wgs = env_int("PSSBAM_GRID_WGS");
+    e->env_want_wgs = env_int("PSSBAM_WANT_WGS");
     *out = e;
     return PSSBAM_OK;
 }
@@ -461,10 +463,11 @@ static int launch_tally(pssbam_engine *e, const uint8_t *d_recs, uint64_t nbytes
 #define LAUNCH_TILED(PSS, KM, LK)                                                                  \
     do {                                                                                           \
         uint32_t cap = P.tile_bytes_cap;                                                           \
-        rc = prep_kernel(tally_tiled<PSS, KM, LK>, e->lds_per_cu, min_cap, 3u, &cap, &occ);        \
+        rc = prep_kernel(tally_tiled<PSS, KM, LK>, e->lds_per_cu, min_cap, e->env_want_wgs > 0 ? (uint32_t)e->env_want_wgs : 3u, &cap, &occ); \
         if (rc == PSSBAM_OK) {                                                                     \
             P.tile_bytes_cap = cap;                                                                \
-            const uint32_t grid = (uint32_t)std::min<uint64_t>(n_tiles, (uint64_t)e->n_cu * occ * mult); \
+            uint32_t grid = (uint32_t)std::min<uint64_t>(n_tiles, (uint64_t)e->n_cu * occ * mult); \
+            if (e->env_grid_wgs > 0) grid = (uint32_t)std::min<uint64_t>(n_tiles, (uint64_t)e->env_grid_wgs); \
             hipLaunchKernelGGL((tally_tiled<PSS, KM, LK>), dim3(grid), dim3(TILED_THREADS), tiled_lds_bytes(cap), e->stream, P); \
         }                                                                                          \
     } while (0)
@@ -575,6 +578,26 @@ extern "C" int pssbam_engine_counters_device(pssbam_engine *e, void **d_counters
     if (!e || !d_counters || !n_u64) return fail(PSSBAM_EINVAL, "null argument");
     *d_counters = e->d_counters;
     *n_u64 = e->n_counters;
+    return PSSBAM_OK;
+}
+
+extern "C" int pssbam_engine_genome_kmer_count(pssbam_engine *e, int klen, uint64_t *counts) {
+    if (!e || !counts) return fail(PSSBAM_EINVAL, "null argument");
+    if (klen < 1 || klen > 12) return fail(PSSBAM_EINVAL, "klen %d outside the device range 1..12", klen);
+    if (!e->d_genome) return fail(PSSBAM_ESTATE, "set_genome has not been called");
+    HIP_TRY(hipSetDevice(e->device));
+    const size_t nb = (size_t)1 << (2 * klen);
+    unsigned long long *d_bins = nullptr;
+    HIP_TRY(hipMalloc(&d_bins, nb * sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(d_bins, 0, nb * sizeof(unsigned long long), e->stream));
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>((e->genome_bytes / GKC_SPAN + 255) / 256 + 1, (uint64_t)e->n_cu * 16);
+    if (klen <= 6) hipLaunchKernelGGL(genome_kmer_kernel<true>, dim3(blocks), dim3(256), 0, e->stream, e->d_genome, e->genome_bytes, klen, d_bins);
+    else hipLaunchKernelGGL(genome_kmer_kernel<false>, dim3(blocks), dim3(256), 0, e->stream, e->d_genome, e->genome_bytes, klen, d_bins);
+    hipError_t le = hipGetLastError();
+    if (le == hipSuccess) le = hipMemcpyAsync(counts, d_bins, nb * sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream);
+    if (le == hipSuccess) le = hipStreamSynchronize(e->stream);
+    (void)hipFree(d_bins);
+    if (le != hipSuccess) return fail(PSSBAM_EHIP, "genome k-mer count failed: %s", hipGetErrorString(le));
     return PSSBAM_OK;
 }
 

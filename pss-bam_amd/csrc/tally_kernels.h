@@ -577,6 +577,53 @@ __global__ void __launch_bounds__(TILED_THREADS) tally_tiled(const TallyParams P
     tally_tiled_body<DO_PSS, DO_KMER, LDS_KMER>(P, kernarg, stage, sheet, table, lut, ctxf, toffs, tgeo, lds_kmer, lds_delta, refs_lds);
 }
 
+// genome-kmer-count (genome-kmer-count.c:69-79): every k-mer start of the device genome.  Each
+// lane walks GKC_SPAN consecutive positions with a rolling 2-bit code; `run` = number of
+// consecutive ACGT bases ending here, a window counts when run >= k.  Contig padding is stored
+// as non-ACGT, so no window spans two contigs.  Bins: LDS histogram for k <= 6, else global.
+constexpr uint32_t GKC_SPAN = 256;
+template <bool LDS_BINS>
+__global__ void __launch_bounds__(256) genome_kmer_kernel(const uint8_t *genome, uint64_t n, int K,
+                                                          unsigned long long *bins) {
+    __shared__ uint32_t lds_bins[LDS_BINS ? 4096 : 1];
+    const uint32_t nb = 1u << (2 * K), mask = nb - 1u;
+    if (LDS_BINS) {
+        for (uint32_t i = threadIdx.x; i < nb; i += blockDim.x) lds_bins[i] = 0u;
+        __syncthreads();
+    }
+    const uint64_t n_spans = (n + GKC_SPAN - 1) / GKC_SPAN;
+    for (uint64_t sp = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; sp < n_spans; sp += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t p0 = sp * GKC_SPAN, p1 = min(n, p0 + GKC_SPAN);
+        // warm-up: the K-1 bases before the span (their windows belong to the previous span)
+        uint32_t code = 0u, run = 0u;
+        for (uint64_t p = p0 >= (uint64_t)(K - 1) ? p0 - (uint64_t)(K - 1) : 0; p < p0; p++) {
+            const uint32_t c = genome[p];
+            run = c < 4u ? run + 1u : 0u;
+            code = ((code << 2) | (c & 3u)) & mask;
+        }
+        for (uint64_t p = p0; p < p1; p += 4) {  // spans start 4-byte aligned (GKC_SPAN % 4 == 0)
+            const uint32_t w = *(const uint32_t *)(genome + p);
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                if (p + b < p1) {
+                    const uint32_t c = (w >> (8 * b)) & 0xFFu;
+                    run = c < 4u ? run + 1u : 0u;
+                    code = ((code << 2) | (c & 3u)) & mask;
+                    if (run >= (uint32_t)K) {  // window [p+b-K+1, p+b] is all ACGT
+                        if (LDS_BINS) atomicAdd(&lds_bins[code], 1u);
+                        else atomicAdd(&bins[code], 1ull);
+                    }
+                }
+            }
+        }
+    }
+    if (LDS_BINS) {
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < nb; i += blockDim.x)
+            if (lds_bins[i]) atomicAdd(&bins[i], (unsigned long long)lds_bins[i]);
+    }
+}
+
 // Upload-time genome transform: toupper() fold (init_genome stores upper case,
 // fasta-genome-io.c:127; process_aln folds again, pss-bam.c:424) followed by the
 // A/C/G/T <-> 0..3 byte swap of record_decode.h.  16 bytes per lane per step.

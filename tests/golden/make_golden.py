@@ -17,7 +17,7 @@ HERE = Path(__file__).resolve().parent
 sys.path.insert(0, str(HERE.parent))
 
 from pssbam_testlib import (FkOpts, PssOpts, build_oracle, fuzz_dataset, have_ref, ref_safe,  # noqa: E402
-                            run_ref_fragkon, run_ref_pss, write_bam, write_fasta, write_sam)
+                            run_ref_fragkon, run_ref_gkc, run_ref_pss, write_bam, write_fasta, write_sam)
 import numpy as np  # noqa: E402
 
 
@@ -76,6 +76,19 @@ def main():
             os.chdir(cwd)
         (HERE / tag).write_text(out)
         manifest["cases"].append({"tool": "fragkon", "dataset": ds, "opts": asdict(o), "stdout": tag})
+
+    for ds, k in (("A", 4), ("A", 3), ("B", 6)):
+        d = manifest["datasets"][ds]
+        tag = f"gkc_{ds}_{k}.txt"
+        import os
+        cwd = os.getcwd()
+        os.chdir(HERE)
+        try:
+            _, out = run_ref_gkc(Path(d["fasta"]), k)
+        finally:
+            os.chdir(cwd)
+        (HERE / tag).write_text(out)
+        manifest["cases"].append({"tool": "genome-kmer-count", "dataset": ds, "klen": k, "stdout": tag})
 
     (HERE / "manifest.json").write_text(json.dumps(manifest, indent=1) + "\n")
     print(f"wrote {len(manifest['cases'])} golden cases to {HERE}")

@@ -116,6 +116,7 @@ class Oracle:
         L.orc_fk_run.restype = C.c_int
         L.orc_fk_run.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(_FkParams), C.c_void_p, C.c_void_p,
                                  C.c_void_p]
+        L.orc_genome_kmer_count.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.orc_pss_rates.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
         L.orc_pss_write_counts.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_void_p, C.c_void_p]
         L.orc_pss_write_rates.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_void_p, C.c_void_p]
@@ -162,6 +163,13 @@ class Oracle:
         if rc != 0:
             raise RuntimeError(f"orc_fk_run failed rc={rc}")
         return k5, k3, st
+
+    def genome_kmer_count(self, genome, klen: int) -> np.ndarray:
+        out = np.zeros(4 ** klen, dtype=np.uint32)
+        rc = self.lib.orc_genome_kmer_count(genome, klen, out.ctypes.data)
+        if rc != 0:
+            raise RuntimeError(f"orc_genome_kmer_count failed rc={rc}")
+        return out
 
     def rates(self, counts: np.ndarray) -> np.ndarray:
         n = counts.shape[0] - 2
@@ -240,6 +248,16 @@ def run_ref_pss(fasta: Path, aln: Path, prefix: Path, o: PssOpts, variant: str =
     rt = Path(f"{prefix}.pss.rates.txt").read_text()
     fwd, rev = parse_counts_text(ct)
     return fwd, rev, ct, rt, pr.stderr
+
+
+def run_ref_gkc(fasta: Path, klen: int, timeout: float = 600.0) -> tuple[np.ndarray, str]:
+    """oracle/_ref/genome-kmer-count -> (counts[4^k] u32, stdout)"""
+    pr = subprocess.run([str(REF_DIR / "genome-kmer-count"), "-f", str(fasta), "-k", str(klen)], capture_output=True,
+                        text=True, timeout=timeout)
+    if pr.returncode != 0:
+        raise RuntimeError(f"reference genome-kmer-count failed ({pr.returncode}): {pr.stderr[-1000:]}")
+    rows = [ln.split("\t") for ln in pr.stdout.splitlines()[1:]]
+    return np.array([int(c) for _, c in rows], dtype=np.uint32), pr.stdout
 
 
 def parse_fragkon_text(text: str) -> tuple[np.ndarray, np.ndarray]:
@@ -465,7 +483,7 @@ def fuzz_dataset(seed: int, n_reads: int = 1500, contig_lens=(5000, 1200, 300), 
     """A genome + alignments that poke at every branch of both process_aln functions.
     Returns (contigs[(id, text)], refs[(name, len)] for the BAM header, recs)."""
     rng = np.random.default_rng(seed)
-    names = ["chrB", "chrA", "scaffold_10"][:len(contig_lens)]
+    names = ["chrB", "chrA", "scaffold_10", "tiny.4", "tiny.5", "tiny.6"][:len(contig_lens)]
     contigs = [(nm, random_contig(rng, ln)) for nm, ln in zip(names, contig_lens)]
     refs = [(nm, len(s)) for nm, s in contigs] + [("chrMissing", 4000)]   # in BAM header, not in FASTA
     recs: list[Rec] = []

@@ -63,3 +63,13 @@ def test_oracle_fragkon_golden(case, oracle):
     oracle.free_genome(g)
     w5, w3 = parse_fragkon_text((GOLD / case["stdout"]).read_text())
     assert np.array_equal(k5, w5) and np.array_equal(k3, w3)
+
+
+@pytest.mark.parametrize("case", [c for c in MANIFEST["cases"] if c["tool"] == "genome-kmer-count"], ids=lambda c: c["stdout"])
+def test_oracle_genome_kmer_count_golden(case, oracle):
+    ds = MANIFEST["datasets"][case["dataset"]]
+    g = oracle.load_genome(GOLD / ds["fasta"])
+    got = oracle.genome_kmer_count(g, case["klen"])
+    oracle.free_genome(g)
+    want = np.array([int(ln.split("\t")[1]) for ln in (GOLD / case["stdout"]).read_text().splitlines()[1:]], dtype=np.uint32)
+    assert np.array_equal(got, want)

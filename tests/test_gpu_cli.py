@@ -116,7 +116,8 @@ def test_reduce_counters_single_engine_is_identity(tmp_path):
     eng.close()
 
 
-@pytest.mark.parametrize("case", [c for c in MANIFEST["cases"]], ids=lambda c: c.get("prefix") or c["stdout"])
+@pytest.mark.parametrize("case", [c for c in MANIFEST["cases"] if c["tool"] != "genome-kmer-count"],
+                         ids=lambda c: c.get("prefix") or c["stdout"])
 def test_cli_reads_sam_text_like_the_reference_pipeline(bins, case, tmp_path):
     """the very SAM files the reference was run on (plain, and gzipped) straight into the front
     ends: byte-identical reports, including every -R case"""
@@ -141,3 +142,29 @@ def test_cli_reads_sam_text_like_the_reference_pipeline(bins, case, tmp_path):
                             capture_output=True, text=True)
         assert pr.returncode == 0, pr.stderr
         assert pr.stdout.replace(ds["sam"] + ".gz", ds["sam"]) == (GOLD / case["stdout"]).read_text()
+
+
+@pytest.mark.parametrize("case", [c for c in MANIFEST["cases"] if c["tool"] == "genome-kmer-count"], ids=lambda c: c["stdout"])
+def test_genome_kmer_count_cli_golden(bins, case, tmp_path):
+    ds = MANIFEST["datasets"][case["dataset"]]
+    shutil.copy(GOLD / ds["fasta"], tmp_path / ds["fasta"])
+    pr = subprocess.run([str(bins / "genome-kmer-count"), "-f", ds["fasta"], "-k", str(case["klen"])], cwd=tmp_path,
+                        capture_output=True, text=True)
+    assert pr.returncode == 0, pr.stderr
+    assert pr.stdout == (GOLD / case["stdout"]).read_text()
+
+
+def test_genome_kmer_count_engine_vs_oracle(oracle, tmp_path):
+    pkg = ge.load_pkg()
+    rng = np.random.default_rng(3)
+    contigs = [(f"c{i}", tl.random_contig(rng, n)) for i, n in enumerate((250_000, 70_001, 513, 9, 3))]
+    fa = tmp_path / "g.fa"
+    tl.write_fasta(fa, contigs)
+    g = oracle.load_genome(fa)
+    eng = pkg.Engine(kmer=dict(klen=4))
+    eng.set_genome_arrays(tl.loaded_contigs(contigs))
+    for k in (1, 2, 4, 6, 7, 10, 12):
+        want = oracle.genome_kmer_count(g, k)
+        assert np.array_equal(eng.genome_kmer_count(k), want.astype(np.uint64)), k
+    eng.close()
+    oracle.free_genome(g)

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from pssbam_testlib import (FkOpts, PssOpts, fuzz_dataset, have_ref, random_fk_opts, random_pss_opts, ref_safe,
-                            run_ref_fragkon, run_ref_pss, write_fasta, write_sam)
+                            run_ref_fragkon, run_ref_gkc, run_ref_pss, write_fasta, write_sam)
 
 pytestmark = pytest.mark.skipif(not have_ref(), reason="oracle/_ref not built")
 
@@ -90,3 +90,15 @@ def test_gz_fasta_and_O2_build_agree(tmp_path, oracle):
     fwd, rev, _ = oracle.pss(g, sam, o)
     oracle.free_genome(g)
     assert np.array_equal(fwd, a[0]) and np.array_equal(rev, a[1])
+
+
+@pytest.mark.parametrize("k", [1, 3, 4, 7, 9])
+def test_genome_kmer_count_restatement_matches_reference(tmp_path, oracle, k):
+    contigs, _, _ = fuzz_dataset(40 + k, 10, contig_lens=(30000, 4000, 600, 50))
+    fa = tmp_path / "g.fa"
+    write_fasta(fa, contigs)
+    g = oracle.load_genome(fa)
+    got = oracle.genome_kmer_count(g, k)
+    oracle.free_genome(g)
+    want, _ = run_ref_gkc(fa, k)
+    assert np.array_equal(got, want) and got.sum() > 20000
