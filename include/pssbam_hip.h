@@ -49,7 +49,7 @@ extern "C" {
 /* kernel selection (diagnostics / tests; 0 lets the engine choose) */
 #define PSSBAM_KERNEL_AUTO 0
 #define PSSBAM_KERNEL_SIMPLE 1  /* lane-per-read, global gathers (any N, any k)          */
-#define PSSBAM_KERNEL_TILED 2   /* LDS-staged record tiles, lane=row tally (N <= 30)     */
+#define PSSBAM_KERNEL_TILED 2   /* LDS-staged record prefixes, lane=row tally (N <= 30)  */
 
 /* pss-bam's option globals, /root/reference/pss-bam.c:12-18 (set by -r -l -L -q -U -D -m) */
 typedef struct pssbam_pss_opts {
@@ -133,7 +133,8 @@ int pssbam_engine_submit(pssbam_engine *e, const void *records, uint64_t nbytes,
                          const uint32_t *offsets, uint32_t n_records);
 
 /* Same with both arrays already resident in device memory; nothing is copied and the
- * buffers must stay valid until pssbam_engine_sync / finish. */
+ * buffers must stay valid until pssbam_engine_sync / finish.  d_records must be 16-byte
+ * aligned and readable up to nbytes rounded up to 16 (any hipMalloc / torch allocation is). */
 int pssbam_engine_submit_device(pssbam_engine *e, const void *d_records, uint64_t nbytes,
                                 const uint32_t *d_offsets, uint32_t n_records);
 

@@ -74,7 +74,6 @@ struct pssbam_engine {
     bool has_rg = false;
     int device = 0;
     int n_cu = 0;
-    uint32_t lds_per_cu = 160u * 1024u;
     hipStream_t stream = nullptr, copy_stream = nullptr;
     bool own_stream = false;
 
@@ -107,7 +106,9 @@ struct pssbam_engine {
     double kernel_ms = 0.0;
     uint64_t kernel_launches = 0;
     // tuning overrides (environment, for experiments)
-    int env_tile_reads = 0, env_tile_cap = 0, env_grid_mult = 0, env_simple_blocks = 0, env_grid_wgs = 0, env_want_wgs = 0;
+    int env_tile_reads = 0, env_grid_mult = 0, env_simple_blocks = 0, env_grid_wgs = 0, env_pieces = 0;
+    uint32_t dev_pieces = 0;       // prefix pieces sampled from a device-resident block
+    uint64_t dev_pieces_avg = 0;   // ... and the mean record size it was sampled at
 };
 
 static void ctx_mask(const char *set, uint32_t (&m)[8]) {
@@ -167,7 +168,6 @@ extern "C" int pssbam_engine_create(const pssbam_config *cfg, pssbam_engine **ou
     hipDeviceProp_t pr;
     HIP_TRY(hipGetDeviceProperties(&pr, dev));
     e->n_cu = pr.multiProcessorCount;
-    if (pr.maxSharedMemoryPerMultiProcessor > 0) e->lds_per_cu = (uint32_t)pr.maxSharedMemoryPerMultiProcessor;
     HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
     e->own_stream = true;
@@ -193,11 +193,10 @@ extern "C" int pssbam_engine_create(const pssbam_config *cfg, pssbam_engine **ou
         HIP_TRY(hipEventCreateWithFlags(&s.consumed, hipEventDisableTiming));
     }
     e->env_tile_reads = env_int("PSSBAM_TILE_READS");
-    e->env_tile_cap = env_int("PSSBAM_TILE_CAP");
     e->env_grid_mult = env_int("PSSBAM_GRID_MULT");
     e->env_simple_blocks = env_int("PSSBAM_SIMPLE_BLOCKS");
     e->env_grid_wgs = env_int("PSSBAM_GRID_WGS");
-    e->env_want_wgs = env_int("PSSBAM_WANT_WGS");
+    e->env_pieces = env_int("PSSBAM_PIECES");
     *out = e;
     return PSSBAM_OK;
 }
@@ -363,34 +362,46 @@ static int resolve_launch_events(pssbam_engine *e) {
     return PSSBAM_OK;
 }
 
-// Fits the dynamic staging window to the kernel's static LDS so that `want_wgs` workgroups
-// share one CU's LDS (160 KiB on gfx950) whenever the tile still fits; returns the occupancy
-// the runtime reports for the final size.
 template <class K>
-static int prep_kernel(K kernel, uint32_t lds_per_cu, uint32_t min_cap, uint32_t want_wgs, uint32_t *cap_io, int *occ) {
-    hipFuncAttributes fa;
-    HIP_TRY(hipFuncGetAttributes(&fa, (const void *)kernel));
-    const uint32_t stat = (uint32_t)fa.sharedSizeBytes;
-    const uint32_t per_wg = lds_per_cu / want_wgs;
-    if (per_wg > stat + STAGE_SLACK + 1024u) {
-        const uint32_t room = ((per_wg - stat - STAGE_SLACK - 256u) / 1024u) * 1024u;  // 256 B: allocation granule slop
-        if (room >= min_cap && room < *cap_io) *cap_io = room;
-    }
-    const uint32_t lds_bytes = tiled_lds_bytes(*cap_io);
+static int prep_kernel(K kernel, uint32_t lds_bytes, int *occ) {
     HIP_TRY(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(occ, kernel, TILED_THREADS, lds_bytes));
     if (*occ < 1) return fail(PSSBAM_EHIP, "kernel does not fit a CU with %u bytes of LDS", lds_bytes);
     return PSSBAM_OK;
 }
 
+// How many 16-byte pieces of a record the tiled kernel must stage so that everything the path
+// reads (through QUAL[0]; the whole record when the -R filter walks the aux fields) is in LDS
+// for typical records: sampled from the first records of a block.  Records that need more take
+// the kernel's out-of-line global-memory path, so this is a performance choice only.
+static uint32_t sample_prefix_pieces(const uint8_t *bytes, uint64_t nbytes, bool whole_record) {
+    uint64_t o = 0, need_max = 64;
+    for (int n = 0; n < 512 && o + 36 <= nbytes; n++) {
+        uint32_t bs, l_seq;
+        memcpy(&bs, bytes + o, 4);
+        if (bs < 32 || o + 4 + (uint64_t)bs > nbytes) break;
+        const uint32_t l_name = bytes[o + 12];
+        uint16_t n_cig;
+        memcpy(&n_cig, bytes + o + 16, 2);
+        memcpy(&l_seq, bytes + o + 20, 4);
+        const uint64_t qual_off = 36ull + l_name + 4ull * n_cig + ((uint64_t)l_seq + 1) / 2;
+        const uint64_t need = whole_record ? 4ull + bs : std::min<uint64_t>(qual_off + 1, 4ull + bs);
+        need_max = std::max(need_max, need);
+        o += 4 + (uint64_t)bs;
+    }
+    const uint64_t pieces = (need_max + 15 + 15) / 16;  // + worst-case misalignment of the record start
+    return (uint32_t)std::min<uint64_t>(std::max<uint64_t>(pieces, 4), 40);
+}
+
 static int launch_tally(pssbam_engine *e, const uint8_t *d_recs, uint64_t nbytes, const uint32_t *d_offs,
-                        uint32_t n_records) {
+                        uint32_t n_records, const uint8_t *host_sample, uint64_t host_sample_bytes) {
     if (!n_records) return PSSBAM_OK;
     const pssbam_config &c = e->cfg;
     TallyParams P{};
     P.recs = d_recs;
     P.offs = d_offs;
     P.n_recs = n_records;
+    P.recs_bytes = nbytes;
     P.tally_mask = c.tally_mask;
     P.genome = e->d_genome;
     P.ref_info = e->d_ref_info;
@@ -440,35 +451,41 @@ static int launch_tally(pssbam_engine *e, const uint8_t *d_recs, uint64_t nbytes
         if (lds_tab) hipLaunchKernelGGL(tally_simple<true>, dim3(blocks), dim3(256), tab_bytes, e->stream, P);
         else hipLaunchKernelGGL(tally_simple<false>, dim3(blocks), dim3(256), 0, e->stream, P);
     } else {
-        // tile geometry from the block's mean record size; records that overflow the
-        // staging window are handled (slowly, correctly) straight from global memory
+        // how much of each record goes through LDS: sampled from the block itself (host copy at
+        // hand for submit(); for device-resident blocks a one-off 64 KiB read-back, remembered
+        // while the mean record size stays put)
         const uint64_t avg = std::max<uint64_t>(40, nbytes / n_records);
-        uint32_t T = avg * 128 <= 40 * 1024 ? 128u : 64u;
+        uint32_t pieces;
+        if (host_sample) {
+            pieces = sample_prefix_pieces(host_sample, host_sample_bytes, e->has_rg);
+        } else {
+            if (!e->dev_pieces || avg * 8 < e->dev_pieces_avg * 7 || avg * 7 > e->dev_pieces_avg * 8) {
+                std::vector<uint8_t> head((size_t)std::min<uint64_t>(nbytes, 64 * 1024));
+                HIP_TRY(hipMemcpyAsync(head.data(), d_recs, head.size(), hipMemcpyDeviceToHost, e->stream));
+                HIP_TRY(hipStreamSynchronize(e->stream));
+                e->dev_pieces = sample_prefix_pieces(head.data(), head.size(), e->has_rg);
+                e->dev_pieces_avg = avg;
+            }
+            pieces = e->dev_pieces;
+        }
+        if (e->env_pieces > 0) pieces = (uint32_t)std::min(std::max(e->env_pieces, 4), 64);
+        uint32_t T = TILED_MAX_T;
         if (e->env_tile_reads > 0) T = std::min<uint32_t>(TILED_MAX_T, (uint32_t)(e->env_tile_reads + 15) / 16 * 16);
-        // staging window: mean tile size + 3 % + 512 B; three workgroups (incl. the static LDS
-        // tables, + 2 KiB k-mer bins) must fit the CU's 160 KiB at 150-bp records
-        uint64_t cap64 = (uint64_t)T * avg + (uint64_t)T * avg / 32 + 512;
-        cap64 = std::min<uint64_t>(cap64, 64 * 1024);
-        if (e->env_tile_cap > 0) cap64 = (uint64_t)e->env_tile_cap;
         P.reads_per_tile = T;
+        P.prefix_pieces = pieces;
         P.ablate = (uint32_t)env_int("PSSBAM_ABLATE");
-        P.tile_bytes_cap = (uint32_t)((cap64 + 1023) & ~1023ull);
         const bool kmer_lds = do_kmer && c.kmer.klen <= KMER_LDS_MAX_K;
         const uint32_t n_tiles = (n_records + T - 1) / T;
-        // smallest window that still holds a mean tile (+16 B of alignment): below it most tiles
-        // would spill to the slow path, so the occupancy target is dropped instead
-        const uint32_t min_cap = (uint32_t)(((uint64_t)T * avg + 16 + 1023) & ~1023ull);
+        const uint32_t lds = tiled_lds_bytes(T, pieces);
         int occ = 0, rc = PSSBAM_OK;
         const int mult = e->env_grid_mult > 0 ? e->env_grid_mult : 1;
 #define LAUNCH_TILED(PSS, KM, LK)                                                                  \
     do {                                                                                           \
-        uint32_t cap = P.tile_bytes_cap;                                                           \
-        rc = prep_kernel(tally_tiled<PSS, KM, LK>, e->lds_per_cu, min_cap, e->env_want_wgs > 0 ? (uint32_t)e->env_want_wgs : 3u, &cap, &occ); \
+        rc = prep_kernel(tally_tiled<PSS, KM, LK>, lds, &occ);                                     \
         if (rc == PSSBAM_OK) {                                                                     \
-            P.tile_bytes_cap = cap;                                                                \
             uint32_t grid = (uint32_t)std::min<uint64_t>(n_tiles, (uint64_t)e->n_cu * occ * mult); \
             if (e->env_grid_wgs > 0) grid = (uint32_t)std::min<uint64_t>(n_tiles, (uint64_t)e->env_grid_wgs); \
-            hipLaunchKernelGGL((tally_tiled<PSS, KM, LK>), dim3(grid), dim3(TILED_THREADS), tiled_lds_bytes(cap), e->stream, P); \
+            hipLaunchKernelGGL((tally_tiled<PSS, KM, LK>), dim3(grid), dim3(TILED_THREADS), lds, e->stream, P); \
         }                                                                                          \
     } while (0)
         if (do_pss && do_kmer) { if (kmer_lds) LAUNCH_TILED(true, true, true); else LAUNCH_TILED(true, true, false); }
@@ -500,7 +517,7 @@ extern "C" int pssbam_engine_submit_device(pssbam_engine *e, const void *d_recor
     if (((uintptr_t)d_records & 15u) || ((uintptr_t)d_offsets & 3u))
         return fail(PSSBAM_EINVAL, "d_records must be 16-byte aligned, d_offsets 4-byte aligned");
     HIP_TRY(hipSetDevice(e->device));
-    return launch_tally(e, (const uint8_t *)d_records, nbytes, d_offsets, n_records);
+    return launch_tally(e, (const uint8_t *)d_records, nbytes, d_offsets, n_records, nullptr, 0);
 }
 
 extern "C" int pssbam_engine_submit(pssbam_engine *e, const void *records, uint64_t nbytes, const uint32_t *offsets,
@@ -534,7 +551,7 @@ extern "C" int pssbam_engine_submit(pssbam_engine *e, const void *records, uint6
                            e->copy_stream));
     HIP_TRY(hipEventRecord(s.copied, e->copy_stream));
     HIP_TRY(hipStreamWaitEvent(e->stream, s.copied, 0));
-    rc = launch_tally(e, s.d_recs, nbytes, s.d_offs, n_records);
+    rc = launch_tally(e, s.d_recs, nbytes, s.d_offs, n_records, (const uint8_t *)records, nbytes);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(s.consumed, e->stream));
     s.busy = true;

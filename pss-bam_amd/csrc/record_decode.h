@@ -30,6 +30,7 @@ struct TallyParams {
     const uint8_t *recs;          // record block
     const uint32_t *offs;         // n_recs + 1 offsets into recs
     uint32_t n_recs;
+    uint64_t recs_bytes;          // bytes of the record block (= offs[n_recs])
     uint32_t tally_mask;          // PSSBAM_TALLY_*
     const uint8_t *genome;        // all contigs, 1 stored byte/base (enc_byte), padded between
     // BAM refID -> where its contig lies, resolved once per header by find_seq semantics:
@@ -57,7 +58,7 @@ struct TallyParams {
     uint32_t off_rev, off_k5, off_k3, off_stats;
     // tiled kernel geometry
     uint32_t reads_per_tile;      // T, multiple of 64
-    uint32_t tile_bytes_cap;      // bytes of the staging buffer, multiple of 1024
+    uint32_t prefix_pieces;       // 16-byte pieces of each record the tiled kernel stages in LDS
     uint32_t ablate;              // diagnostics: phases to skip (results are wrong when non-zero)
 };
 

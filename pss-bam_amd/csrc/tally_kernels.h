@@ -4,20 +4,25 @@
 //                 global memory, counts into an LDS table (or global atomics when the
 //                 table would not fit).  Any -r N, any k.  Fallback + cross-check.
 //  tally_tiled  : the production kernel for N <= 30.  Persistent workgroups walk tiles
-//                 of T consecutive reads:
-//                   1. STAGE   the tile's raw BAM bytes are streamed into LDS by LDS-DMA
-//                              (global_load_lds_dwordx4: 1 KiB per wave-instruction, no
-//                              VGPR round trip); with two staging buffers the next tile's
-//                              DMA is in flight while this tile is decoded and tallied.
-//                              This is the only bulk HBM traffic of the kernel.
-//                   2. CODES   a lane pair per read (one lane per alignment end): decode
-//                              + filters from LDS, gather the end's reference window
-//                              (N+2 bytes) from the device genome, turn the N+2 positions
-//                              into one byte each = (cell << 1 | table) or CODE_NONE, through a
-//                              272-byte LDS lookup table indexed by (read nibble,
-//                              reference code, strand), and store the 2 x 32 bytes of the
-//                              read's row of the code sheet.  K-mer windows are tallied
-//                              here too (one per lane of the pair).
+//                 of T = 128 consecutive reads:
+//                   1. STAGE   LDS-DMA (global_load_lds_dwordx4) with a PER-LANE source address:
+//                              lane q of the tile's piece list fetches 16-byte piece q % P of
+//                              record q / P, and the hardware packs the pieces of one
+//                              wave-instruction contiguously in LDS -- so record j's first
+//                              P*16 bytes (header, name, CIGAR, SEQ, QUAL[0]: everything the
+//                              path reads) land densely at stage + j*P*16.  The ~150 QUAL bytes
+//                              of a 150-bp record are never fetched: HBM traffic is BELOW the
+//                              record size, the staging buffer is half of a whole-record tile,
+//                              and consecutive lanes still read consecutive addresses (cheap
+//                              for the texture addresser).  The next tile's DMA is issued as
+//                              soon as CODES-A is done with the buffer.
+//                   2. CODES   a lane pair per read (one lane per alignment end).  Part A:
+//                              decode + filters from LDS, the end's reference window
+//                              (32 bytes) and k-mer window gathered from the device genome,
+//                              SEQ nibbles into registers.  Part B: one byte per window
+//                              position = (cell << 1 | table) or CODE_NONE through a 272-byte
+//                              LDS lookup table indexed by (read nibble, reference code,
+//                              strand), written as the read's row of the code sheet.
 //                   3. COLUMNS wave-per-read, lane = column of the code sheet: each lane
 //                              owns one (end, position) and bumps ITS word of a
 //                              [cell,table][row] LDS table.  Lanes of one wave-instruction
@@ -170,18 +175,19 @@ __global__ void __launch_bounds__(256) tally_simple(const TallyParams P) {
 // ---------------------------------------------------------------------------------------
 // tally_tiled
 // ---------------------------------------------------------------------------------------
-// LDS objects.  Only the staging buffer is dynamic (extern) LDS; everything the kernel touches
-// while an LDS-DMA transfer is in flight is a SEPARATE static object, so the compiler can prove
-// those accesses do not alias the DMA destination and does not fence them behind vmcnt(0):
-//   stage  (dynamic) : tile_bytes_cap + STAGE_SLACK   raw BAM bytes of the current tile
-//   sheet  : TILED_MAX_T * 64                         code sheet [read][end*32 + position]
-//   table  : 34 * 32 * 4                              [(cell<<1)|table][row] u32; rows 32,33 = trash bin
-//                                                     for "no count" codes, so the column pass has no branches
-//   lut    : PAIR_LUT_BYTES                           (strand, nibble row, ref code) -> code
-//   ctxf   : 256                                      -U / -D membership flags per stored genome byte
-//   toffs  : (TILED_MAX_T + 4) * 4, tgeo : 16         the tile's record offsets, the next tile's geometry
-//   kmer   : 2 * 4^KMER_LDS_MAX_K * 4                 (LDS_KMER variants only)
-//   refs   : (REF_LDS_ENTRIES + 1) * 16               contig info of the first BAM references
+// LDS objects.  Only the staging buffer is dynamic (extern) LDS; everything else is a
+// separate static object:
+//   stage  (dynamic) : T * P * 16 + STAGE_SLACK          first P pieces of every record of the tile
+//   sheet  : TILED_MAX_T * 64                             code sheet [read][end*32 + position]
+//   table  : 34 * 32 * 4                                  [(cell<<1)|table][row] u32; rows 32,33 = trash bin
+//                                                         for "no count" codes, so the column pass has no branches
+//   lut    : PAIR_LUT_BYTES                               (strand, nibble row, ref code) -> code
+//   ctxf   : 256                                          -U / -D membership flags per stored genome byte
+//   toffs  : 2 * (TILED_MAX_T + 4) * 4                    record offsets of this tile and the next
+//   kmer   : 2 * 4^KMER_LDS_MAX_K * 4                     (LDS_KMER variants only)
+//   refs   : (REF_LDS_ENTRIES + 1) * 16                   contig info of the first BAM references
+__host__ __device__ inline uint32_t tiled_lds_bytes(uint32_t T, uint32_t pieces) { return T * pieces * 16u + STAGE_SLACK; }
+
 // Four dwords at 4-byte alignment: gfx950 global loads only need dword alignment, so this
 // compiles to ONE global_load_dwordx4 per lane.  A gather's cost in the texture addresser is per
 // wave-instruction and per distinct line touched -- nine single-dword gathers of a 36-byte
@@ -190,29 +196,30 @@ struct __attribute__((packed, aligned(4))) Quad { uint32_t v[4]; };
 
 constexpr uint32_t TILED_MAX_T = 128;
 static_assert(TILED_MAX_T * 2 == TILED_THREADS, "CODES maps one (read, end) pair to each thread");
-__host__ __device__ inline uint32_t tiled_stage_stride(uint32_t cap) { return (cap + STAGE_SLACK + 15u) & ~15u; }
-__host__ __device__ inline uint32_t tiled_lds_bytes(uint32_t cap) { return tiled_stage_stride(cap); }
 
-// Streams bytes [base16, base16 + nbytes) of the record block into `stage` (nbytes is a
-// multiple of 16; the tail chunk is lane-predicated so nothing beyond it is read).
+// STAGE: piece q of the tile (q = record * P + piece) goes to stage + q*16.  Each wave-instruction
+// moves 64 consecutive pieces (1 KiB of LDS); a lane's source is its record's 16-byte aligned
+// start + 16 * piece.  Pieces that would start beyond the record block are not issued.
 //
 // The LDS-DMA instruction is issued through inline asm on purpose.  hipcc's waitcnt pass
 // fences EVERY later LDS access behind vmcnt(0) once it has seen an LDS-DMA it cannot
 // disambiguate (no alias-scope metadata reaches it from HIP source), which would serialise
-// the transfer against the COLUMNS pass it is meant to hide behind.  The asm form is
-// invisible to that pass; ordering is ours: the kernel waits with an explicit
-// `s_waitcnt vmcnt(0)` + barrier before any lane reads `stage`, and nothing else writes
-// `stage`.  (Compiler-counted vmcnt(N) waits for its own loads only get stricter with
-// unseen younger/older operations in flight, never weaker: vmcnt retires in order.)
-__device__ __forceinline__ void stage_tile_dma(const uint8_t *recs, uint32_t base16, uint32_t nbytes, uint8_t *stage,
-                                               uint32_t wave, uint32_t lane) {
-    const uint32_t n_chunks = (nbytes + 1023u) >> 10;
+// the transfer against the passes it is meant to hide behind.  The asm form is invisible to
+// that pass; ordering is ours: the kernel waits with an explicit `s_waitcnt vmcnt(0)` + barrier
+// before any lane reads `stage`, and nothing else writes `stage`.  (Compiler-counted vmcnt(N)
+// waits for its own loads only get stricter with unseen operations in flight, never weaker:
+// vmcnt retires in order.)
+__device__ __forceinline__ void stage_tile_dma(const uint8_t *recs, uint64_t recs_limit, const uint32_t *tile_offs,
+                                               uint32_t count, uint32_t pieces, uint8_t *stage, uint32_t tid) {
+    const uint32_t n_pieces = count * pieces;
     const uint32_t lds0 = (uint32_t)(uintptr_t)stage;  // LDS byte address (low half of the generic pointer)
-    for (uint32_t c = wave; c < n_chunks; c += TILED_WAVES) {
-        const uint32_t off = (c << 10) + (lane << 4);
-        if (off < nbytes) {
-            const uint8_t *src = recs + base16 + off;
-            const uint32_t m0v = __builtin_amdgcn_readfirstlane(lds0 + (c << 10));
+    for (uint32_t q0 = (tid & ~63u); q0 < n_pieces; q0 += TILED_THREADS) {
+        const uint32_t q = q0 + (tid & 63u);
+        const uint32_t j = min(q / pieces, count - 1u), pc = q - (q / pieces) * pieces;
+        const uint64_t a = (uint64_t)(tile_offs[j] & ~15u) + 16u * pc;
+        if (q < n_pieces && a + 16u <= recs_limit) {
+            const uint8_t *src = recs + a;
+            const uint32_t m0v = __builtin_amdgcn_readfirstlane(lds0 + (q0 << 4));
             asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(m0v) : "memory");
             // (m0 is written: gfx950 DS instructions do not read it and hipcc keeps nothing live in
             //  it in this kernel -- checked in the ISA; naming it as a clobber is rejected as reserved)
@@ -252,10 +259,11 @@ __device__ __forceinline__ void tally_tiled_body(const TallyParams &P, const Tal
                                                  uint8_t *__restrict__ stage, uint8_t *__restrict__ sheet,
                                                  uint32_t *__restrict__ table, uint8_t *__restrict__ lut,
                                                  uint8_t *__restrict__ ctxf, uint32_t *__restrict__ toffs,
-                                                 uint32_t *__restrict__ tgeo, uint32_t *__restrict__ lds_kmer,
+                                                 uint32_t *__restrict__ lds_kmer,
                                                  int32_t *__restrict__ lds_delta, uint4 *__restrict__ refs_lds) {
     const uint32_t T = P.reads_per_tile;   // <= TILED_MAX_T
-    const uint32_t cap = P.tile_bytes_cap;
+    const uint32_t pieces = P.prefix_pieces;  // 16-byte pieces staged per record
+    const uint64_t recs_limit = (P.recs_bytes + 15ull) & ~15ull;  // the block is readable up to here
     const uint32_t ablate = P.ablate;      // diagnostics only (PSSBAM_ABLATE): 1 no COLUMNS, 2 no position loop, 4 no CODES
 
     const uint32_t tid = threadIdx.x;
@@ -305,44 +313,38 @@ __device__ __forceinline__ void tally_tiled_body(const TallyParams &P, const Tal
 
     const uint32_t n_tiles = (P.n_recs + T - 1u) / T;
     const uint32_t tstride = gridDim.x;
-    auto geom = [&](uint32_t o_first, uint32_t o_last, uint32_t &base16, uint32_t &staged) {
-        base16 = o_first & ~15u;
-        staged = min((o_last - base16 + 15u) & ~15u, cap);
-    };
     // software pipeline over this workgroup's tiles k0, k0+stride, ...:
-    //   cur_*  geometry of the tile being processed (its bytes are / will be in `stage`)
-    //   off_a/b  this thread's slice of the tile's offsets, loaded one tile ahead (VGPRs)
-    //   geo    offs[] at the ends of the tile AFTER the next one, loaded two tiles ahead by lanes 0/1
+    //   toffs[par]      offsets of the tile being processed, toffs[par^1] those of the next one
+    //                   (written from VGPRs that were loaded one tile earlier)
+    //   stage           pieces of the tile being processed; refilled for the next tile as soon as
+    //                   CODES-A has read everything it needs
     uint32_t tile = blockIdx.x;
-    uint32_t cur_base16 = 0, cur_staged = 0;
-    uint32_t off_a = 0, off_b = 0, geo = 0;
+    uint32_t off_a = 0;
+    const uint32_t TOFF = TILED_MAX_T + 4u;  // stride between the two offset buffers
     auto load_offsets = [&](uint32_t t) {
         const uint32_t r0 = t * T;
         if (tid <= T && r0 + tid <= P.n_recs) off_a = P.offs[r0 + tid];
-        if (tid + TILED_THREADS <= T && r0 + tid + TILED_THREADS <= P.n_recs) off_b = P.offs[r0 + tid + TILED_THREADS];
     };
-    auto load_geo = [&](uint32_t t) {
-        if (tid < 2u) geo = P.offs[tid == 0u ? t * T : min(t * T + T, P.n_recs)];
-    };
+    auto tile_count = [&](uint32_t t) { return min(T, P.n_recs - t * T); };
+    __syncthreads();  // LDS tables are set up
     if (tile < n_tiles) {
-        geom(P.offs[tile * T], P.offs[min(tile * T + T, P.n_recs)], cur_base16, cur_staged);
         load_offsets(tile);
-        stage_tile_dma(P.recs, cur_base16, cur_staged, stage, wave, lane);
-        if (tile + tstride < n_tiles) load_geo(tile + tstride);
+        if (tid <= T) toffs[tid] = off_a;
+        __syncthreads();
+        stage_tile_dma(P.recs, recs_limit, toffs, tile_count(tile), pieces, stage, tid);
+        if (tile + tstride < n_tiles) load_offsets(tile + tstride);
     }
 
-    for (; tile < n_tiles; tile += tstride) {
+    for (uint32_t it = 0; tile < n_tiles; tile += tstride, it++) {
+        const uint32_t par = it & 1u;
+        const uint32_t *cur_offs = toffs + par * TOFF;
         const uint32_t r0 = tile * T;
         const uint32_t count = min(T, P.n_recs - r0);
         const uint32_t next = tile + tstride;
 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // DMA pieces + offset loads of this wave are in
-        if (tid <= T) toffs[tid] = off_a;
-        if (tid + TILED_THREADS <= T) toffs[tid + TILED_THREADS] = off_b;
-        if (tid < 2u) tgeo[tid] = geo;
+        if (next < n_tiles && tid <= T) toffs[(par ^ 1u) * TOFF + tid] = off_a;  // next tile's offsets
         __syncthreads();  // everyone's DMA landed; previous COLUMNS pass is over
-        uint32_t nxt_base16 = 0, nxt_staged = 0;
-        if (next < n_tiles) geom(tgeo[0], tgeo[1], nxt_base16, nxt_staged);
 
         // ---- CODES, part A: everything that reads `stage` ---------------------------------------
         // A lane pair per read (TILED_MAX_T * 2 == TILED_THREADS: one (read, end) per thread).
@@ -351,12 +353,18 @@ __device__ __forceinline__ void tally_tiled_body(const TallyParams &P, const Tal
         const bool lane_on = tid < 2u * T && !(ablate & 4u);
         const bool in_tile = lane_on && j < count;
         uint32_t o0 = 0, o1 = 0;
-        if (in_tile) { o0 = toffs[j]; o1 = toffs[j + 1]; }
-        const bool in_stage = in_tile && (o1 - cur_base16 <= cur_staged);
-        // records outside the tile / the staging window decode a harmless dummy (offset 0, length
-        // 0 -> malformed -> dead) so the lanes of a wave stay on one path
-        LdsBytes src{stage, in_stage ? o0 - cur_base16 : 0u};
-        const RecHdr h = decode_hdr_lds(src, in_stage ? o1 - o0 : 0u);
+        if (in_tile) { o0 = cur_offs[j]; o1 = cur_offs[j + 1]; }
+        // record j's first `pieces` 16-byte pieces sit at stage + j*pieces*16, starting at its
+        // 16-byte aligned address: byte x of the record is at offset (o0 & 15) + x
+        const uint32_t avail = pieces * 16u - (o0 & 15u);       // record bytes present in LDS
+        const bool hdr_ok = in_tile && o1 - o0 >= 36u && avail >= 48u;
+        // lanes without a usable record decode a harmless dummy (offset 0, length 0 -> malformed ->
+        // dead) so the lanes of a wave stay on one path
+        LdsBytes src{stage, hdr_ok ? j * pieces * 16u + (o0 & 15u) : 0u};
+        const RecHdr h = decode_hdr_lds(src, hdr_ok ? o1 - o0 : 0u);
+        // everything the path reads ends at QUAL[0] (the -R filter walks the aux fields: whole record)
+        const uint32_t needed = P.rg ? o1 - o0 : h.qual_off + 1u;
+        const bool in_stage = hdr_ok && needed <= avail;
         Plan pl = plan_head<DO_PSS, DO_KMER>(P, src, h, RefsLdsCached{refs_lds, P.ref_info, n_ref_cached, (uint32_t)P.n_ref});
         if (!in_stage) { pl.status = RS_LIVE; pl.live = pl.pss_cand = pl.fk5 = pl.fk3 = false; }
         // this end's reference window, issued for every candidate before the -U/-D test so the
@@ -412,14 +420,12 @@ __device__ __forceinline__ void tally_tiled_body(const TallyParams &P, const Tal
             ev_over = tally_overflow_record<DO_PSS, DO_KMER, LDS_KMER>(kernarg, o0, o1, table, lds_kmer);
         __syncthreads();
 
-        // every wave is done with `stage` and `toffs`: the next tile's DMA and offset loads start
-        // now and land behind the rest of CODES and the COLUMNS pass
+        // every wave is done with `stage`: the next tile's DMA starts now (its offsets were put
+        // into LDS before the barrier at the top) and lands behind the rest of CODES and COLUMNS;
+        // the offsets of the tile after that go into VGPRs
         if (next < n_tiles) {
-            load_offsets(next);
-            stage_tile_dma(P.recs, nxt_base16, nxt_staged, stage, wave, lane);
-            if (next + tstride < n_tiles) load_geo(next + tstride);
-            cur_base16 = nxt_base16;
-            cur_staged = nxt_staged;
+            stage_tile_dma(P.recs, recs_limit, toffs + (par ^ 1u) * TOFF, tile_count(next), pieces, stage, tid);
+            if (next + tstride < n_tiles) load_offsets(next + tstride);
         }
 
         // ---- CODES, part B: registers + genome + LUT only ------------------------------------------
@@ -567,14 +573,13 @@ __global__ void __launch_bounds__(TILED_THREADS) tally_tiled(const TallyParams P
     __shared__ uint32_t table[TABLE_WORDS];
     __shared__ __attribute__((aligned(16))) uint8_t lut[PAIR_LUT_BYTES];
     __shared__ uint8_t ctxf[256];
-    __shared__ uint32_t toffs[TILED_MAX_T + 4u];
-    __shared__ uint32_t tgeo[4];   // [0] = offs[first read of the next tile], [1] = offs[one past its last]
+    __shared__ uint32_t toffs[2u * (TILED_MAX_T + 4u)];
     __shared__ uint32_t lds_kmer[LDS_KMER ? 2u * (1u << (2 * KMER_LDS_MAX_K)) : 1u];
     __shared__ int32_t lds_delta[ST_USED];
     __shared__ uint4 refs_lds[REF_LDS_ENTRIES + 1];
     // the kernel's single argument, as it lies in the kernarg segment (for the out-of-line path)
     const TallyParams *kernarg = (const TallyParams *)__builtin_amdgcn_kernarg_segment_ptr();
-    tally_tiled_body<DO_PSS, DO_KMER, LDS_KMER>(P, kernarg, stage, sheet, table, lut, ctxf, toffs, tgeo, lds_kmer, lds_delta, refs_lds);
+    tally_tiled_body<DO_PSS, DO_KMER, LDS_KMER>(P, kernarg, stage, sheet, table, lut, ctxf, toffs, lds_kmer, lds_delta, refs_lds);
 }
 
 // genome-kmer-count (genome-kmer-count.c:69-79): every k-mer start of the device genome.  Each

@@ -49,6 +49,8 @@ int run_tally(const pssbam_config *cfg, Genome *genome, const char *aln_path, in
     void *buf_base = NULL;
     size_t buf_bytes = 0;
     const double t0 = now_s();
+    double t_mark = t0, t_open = 0, t_engine = 0, t_register = 0, t_read = 0, t_submit = 0, t_finish = 0;
+    const int verbose = getenv("PSSBAM_STATS") != NULL;
     memset(res, 0, sizeof *res);
     if (n_gpus < 1) n_gpus = 1;
     if (n_gpus > 64) n_gpus = 64;
@@ -68,6 +70,7 @@ int run_tally(const pssbam_config *cfg, Genome *genome, const char *aln_path, in
         fprintf(stderr, "Error: Unable to open %s: %s\n", aln_path, err);
         return -1;
     }
+    t_open = now_s() - t_mark; t_mark = now_s();
     for (int g = 0; g < n_gpus; g++) {
         pssbam_config c = *cfg;
         c.device = g;
@@ -76,16 +79,20 @@ int run_tally(const pssbam_config *cfg, Genome *genome, const char *aln_path, in
             goto done;
         }
     }
-    if (rd) {
+    t_engine = now_s() - t_mark; t_mark = now_s();
+    if (rd && !getenv("PSSBAM_NO_PIN")) {
         bam_reader_buffer(rd, &buf_base, &buf_bytes);
         registered = pssbam_host_register(buf_base, buf_bytes) == 0; /* best effort: pageable works too */
     }
+    t_register = now_s() - t_mark;
 
     for (int turn = 0;; turn++) {
         const uint8_t *recs;
         const uint32_t *offs;
         size_t nbytes;
+        t_mark = now_s();
         int64_t n = rd ? bam_reader_next(rd, &recs, &offs, &nbytes) : sam_reader_next(sd, &recs, &offs, &nbytes);
+        t_read += now_s() - t_mark; t_mark = now_s();
         if (n < 0) {
             fprintf(stderr, "Error: %s: %s\n", aln_path, rd ? bam_reader_error(rd) : sam_reader_error(sd));
             goto done;
@@ -107,7 +114,9 @@ int run_tally(const pssbam_config *cfg, Genome *genome, const char *aln_path, in
             fprintf(stderr, "Error: GPU engine: %s\n", pssbam_last_error());
             goto done;
         }
+        t_submit += now_s() - t_mark;
     }
+    t_mark = now_s();
     if (refs_sent < 0) { /* no alignment at all: the engines still need a (possibly empty) table to finish */
         const int32_t n_ref = rd ? bam_reader_header(rd)->n_ref : sam_reader_n_ref(sd);
         const char *const *names = rd ? (const char *const *)bam_reader_header(rd)->ref_name : sam_reader_ref_names(sd);
@@ -131,6 +140,10 @@ int run_tally(const pssbam_config *cfg, Genome *genome, const char *aln_path, in
         fprintf(stderr, "Error: GPU engine: %s\n", pssbam_last_error());
         goto done;
     }
+    t_finish = now_s() - t_mark;
+    if (verbose)
+        fprintf(stderr, "[pssbam] phases: open %.3f engine+genome %.3f pin %.3f read(wait) %.3f submit %.3f reduce+finish %.3f s\n",
+                t_open, t_engine, t_register, t_read, t_submit, t_finish);
     res->inflate_s = rd ? bam_reader_inflate_seconds(rd) : 0.0;
     if (sd) res->stats[PSSBAM_ST_PARSE_SKIP] += sam_reader_lines_skipped(sd), res->stats[PSSBAM_ST_RECORDS] += sam_reader_lines_skipped(sd);
     res->n_gpus = n_gpus;

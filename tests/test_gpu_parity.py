@@ -178,8 +178,8 @@ def test_edges_empty_ragged_accumulate_reset(pkg, oracle, tmp_path):
 
 
 def test_tile_overflow_path(pkg, oracle, tmp_path, monkeypatch):
-    """records larger than the LDS staging window take the global-memory path of the
-    tiled kernel; force it with a tiny window"""
+    """records whose needed prefix exceeds what the tiled kernel stages in LDS take its
+    out-of-line global-memory path; force that with a tiny prefix"""
     contigs, refs, recs = tl.fuzz_dataset(77, 1500)
     fa, sam = tmp_path / "g.fa", tmp_path / "a.sam"
     tl.write_fasta(fa, contigs)
@@ -191,7 +191,7 @@ def test_tile_overflow_path(pkg, oracle, tmp_path, monkeypatch):
     oracle.free_genome(g)
     raw = tl.raw_records(refs, recs)
     monkeypatch.setenv("PSSBAM_TILE_READS", "64")
-    monkeypatch.setenv("PSSBAM_TILE_CAP", "2048")
+    monkeypatch.setenv("PSSBAM_PIECES", "5")     # 80 bytes per record in LDS: most records spill
     got = _engine_tables(pkg, contigs, refs, raw, pss=_pss_dict(po), kmer=_fk_dict(ko), kernel=pkg.KERNEL_TILED)
     _check_pss(got, wf, wr, st)
     assert np.array_equal(got.k5, w5.astype(np.uint64)) and np.array_equal(got.k3, w3.astype(np.uint64))
