@@ -244,7 +244,7 @@ def main():
             "kernel_ms_per_launch": kernel_ms / max(n_launch, 1),
             "launches_timed": n_launch,
         },
-        "stats_last_step": stats,
+        "stats_last_step": stats,   # slow_path = records the tiled kernel read from global memory
     }
 
     # ---- CPU baseline: the reference itself on this box's host, on a bounded prefix -----------

@@ -96,6 +96,8 @@ enum {
     PSSBAM_ST_KMER_OK = 6,     /* fragkon process_aln returns 0                          */
     PSSBAM_ST_KMER_FILTERED = 7,/* fragkon process_aln returns 2                         */
     PSSBAM_ST_KMER_FAIL = 8,   /* fragkon process_aln returns -1 (non-ACGT in a k-mer)   */
+    PSSBAM_ST_SLOW_PATH = 9,   /* diagnostics: records the tiled kernel had to read from
+                                  global memory (needed prefix larger than what it stages) */
     PSSBAM_ST_N = 16
 };
 

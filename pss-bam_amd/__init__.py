@@ -25,7 +25,7 @@ LIB_SYNTH = PKG_DIR / "libpssbam_synth.so"
 TALLY_PSS, TALLY_KMER = 1, 2
 KERNEL_AUTO, KERNEL_SIMPLE, KERNEL_TILED = 0, 1, 2
 ST_NAMES = ["records", "rg_dropped", "parse_skip", "no_contig", "pss_ok", "pss_filtered", "kmer_ok",
-            "kmer_filtered", "kmer_fail"]
+            "kmer_filtered", "kmer_fail", "slow_path"]
 ST_N = 16
 
 # every symbol include/pssbam_hip.h declares (checked by tests/test_cabi.py)

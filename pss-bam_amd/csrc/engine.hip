@@ -376,7 +376,7 @@ static int prep_kernel(K kernel, uint32_t lds_bytes, int *occ) {
 // the kernel's out-of-line global-memory path, so this is a performance choice only.
 static uint32_t sample_prefix_pieces(const uint8_t *bytes, uint64_t nbytes, bool whole_record) {
     uint64_t o = 0, need_max = 64;
-    for (int n = 0; n < 512 && o + 36 <= nbytes; n++) {
+    for (int n = 0; n < 4096 && o + 36 <= nbytes; n++) {
         uint32_t bs, l_seq;
         memcpy(&bs, bytes + o, 4);
         if (bs < 32 || o + 4 + (uint64_t)bs > nbytes) break;
@@ -460,7 +460,7 @@ static int launch_tally(pssbam_engine *e, const uint8_t *d_recs, uint64_t nbytes
             pieces = sample_prefix_pieces(host_sample, host_sample_bytes, e->has_rg);
         } else {
             if (!e->dev_pieces || avg * 8 < e->dev_pieces_avg * 7 || avg * 7 > e->dev_pieces_avg * 8) {
-                std::vector<uint8_t> head((size_t)std::min<uint64_t>(nbytes, 64 * 1024));
+                std::vector<uint8_t> head((size_t)std::min<uint64_t>(nbytes, 1024 * 1024));
                 HIP_TRY(hipMemcpyAsync(head.data(), d_recs, head.size(), hipMemcpyDeviceToHost, e->stream));
                 HIP_TRY(hipStreamSynchronize(e->stream));
                 e->dev_pieces = sample_prefix_pieces(head.data(), head.size(), e->has_rg);

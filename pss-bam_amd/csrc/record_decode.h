@@ -67,7 +67,7 @@ struct TallyParams {
 // one unit from the OK slot(s) to its own slot (wrapping u64 arithmetic), so the common case
 // costs no instruction at all.
 enum { ST_RECORDS = 0, ST_RG_DROPPED, ST_PARSE_SKIP, ST_NO_CONTIG, ST_PSS_OK, ST_PSS_FILTERED,
-       ST_KMER_OK, ST_KMER_FILTERED, ST_KMER_FAIL, ST_USED };
+       ST_KMER_OK, ST_KMER_FILTERED, ST_KMER_FAIL, ST_SLOW_PATH, ST_USED };
 
 // ---- byte sources -------------------------------------------------------------------
 // A record is read through one of these; both tolerate any alignment and never touch

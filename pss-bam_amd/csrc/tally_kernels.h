@@ -213,9 +213,12 @@ __device__ __forceinline__ void stage_tile_dma(const uint8_t *recs, uint64_t rec
                                                uint32_t count, uint32_t pieces, uint8_t *stage, uint32_t tid) {
     const uint32_t n_pieces = count * pieces;
     const uint32_t lds0 = (uint32_t)(uintptr_t)stage;  // LDS byte address (low half of the generic pointer)
+    // q / pieces by multiply-shift: exact for q < 2^13 and pieces <= 64 ((pieces-1) * q < 2^20)
+    const uint32_t magic = ((1u << 20) + pieces - 1u) / pieces;
     for (uint32_t q0 = (tid & ~63u); q0 < n_pieces; q0 += TILED_THREADS) {
         const uint32_t q = q0 + (tid & 63u);
-        const uint32_t j = min(q / pieces, count - 1u), pc = q - (q / pieces) * pieces;
+        const uint32_t jq = (q * magic) >> 20;
+        const uint32_t j = min(jq, count - 1u), pc = q - jq * pieces;
         const uint64_t a = (uint64_t)(tile_offs[j] & ~15u) + 16u * pc;
         if (q < n_pieces && a + 16u <= recs_limit) {
             const uint8_t *src = recs + a;
@@ -416,8 +419,25 @@ __device__ __forceinline__ void tally_tiled_body(const TallyParams &P, const Tal
             ksh = (uint32_t)(ka & 3ull);
         }
         uint32_t ev_over = 0u;  // events of a record handled by the out-of-line path
-        if (in_tile && !in_stage && e == 0u)
+        if (in_tile && !in_stage && e == 0u) {
             ev_over = tally_overflow_record<DO_PSS, DO_KMER, LDS_KMER>(kernarg, o0, o1, table, lds_kmer);
+            atomicAdd(&lds_delta[ST_SLOW_PATH], 1);
+        }
+        // First use of the gathered registers happens HERE, before the next tile's DMA is issued:
+        // vmcnt retires in order and hipcc's counted wait for these loads cannot see the
+        // asm-issued DMA pieces, so a wait placed after the DMA issue would also wait for the
+        // whole transfer and serialise it against CODES-B / COLUMNS.
+#pragma unroll
+        for (int k = 0; k < WIN_DWORDS - 1; k++) gw[k] = __builtin_amdgcn_alignbyte(gw[k + 1], gw[k], gsh);
+#pragma unroll
+        for (int k = 0; k < 3; k++) kw[k] = __builtin_amdgcn_alignbyte(kw[k + 1], kw[k], ksh);
+        // pin those uses here (the scheduler would otherwise sink them below the DMA issue)
+#pragma unroll
+        for (int k = 0; k < WIN_DWORDS - 1; k++) asm volatile("" : "+v"(gw[k]));
+        if (DO_KMER) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) asm volatile("" : "+v"(kw[k]));
+        }
         __syncthreads();
 
         // every wave is done with `stage`: the next tile's DMA starts now (its offsets were put
@@ -430,8 +450,6 @@ __device__ __forceinline__ void tally_tiled_body(const TallyParams &P, const Tal
 
         // ---- CODES, part B: registers + genome + LUT only ------------------------------------------
         {
-#pragma unroll
-            for (int k = 0; k < WIN_DWORDS - 1; k++) gw[k] = __builtin_amdgcn_alignbyte(gw[k + 1], gw[k], gsh);
             // first context base next to the alignment: left window byte 1 (s-1), right window byte 30 (s+L)
             const uint32_t own1 = e ? (gw[7] >> 16) & 0xFFu : (gw[0] >> 8) & 0xFFu;
             const uint32_t other1 = (uint32_t)__shfl_xor((int)own1, 1);
@@ -492,8 +510,6 @@ __device__ __forceinline__ void tally_tiled_body(const TallyParams &P, const Tal
             }
             bool kmer_ok = true;
             if (kmer_try) {
-#pragma unroll
-                for (int k = 0; k < 3; k++) kw[k] = __builtin_amdgcn_alignbyte(kw[k + 1], kw[k], ksh);
                 // bin = base-4 number of the k bases read left to right (kmer.c:184-214); for a
                 // reverse-strand read the window is reverse-complemented (fragkon.c:156-160)
                 uint32_t bin = 0u, bad = 0u;
