@@ -389,8 +389,11 @@ static uint32_t sample_prefix_pieces(const uint8_t *bytes, uint64_t nbytes, bool
         need_max = std::max(need_max, need);
         o += 4 + (uint64_t)bs;
     }
-    const uint64_t pieces = (need_max + 15 + 15) / 16;  // + worst-case misalignment of the record start
-    return (uint32_t)std::min<uint64_t>(std::max<uint64_t>(pieces, 4), 40);
+    uint64_t pieces = (need_max + 15 + 15) / 16;  // + worst-case misalignment of the record start
+    // records sit pieces*16 bytes apart in LDS: an even piece count puts every record start of a
+    // wave on few banks (pieces = 8 -> all on one); an odd count spreads them over 8
+    pieces |= 1;
+    return (uint32_t)std::min<uint64_t>(std::max<uint64_t>(pieces, 5), 41);
 }
 
 static int launch_tally(pssbam_engine *e, const uint8_t *d_recs, uint64_t nbytes, const uint32_t *d_offs,
