@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=2_000_000, help="reads timed on the host reference")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--scale-genome", type=float, default=1.0)
+    ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the counter reduce even with one rank")
     args = ap.parse_args()
 
     import numpy as np
@@ -89,8 +90,12 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU implementation")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     cd = synth.config(args.config, sorted_=not args.unsorted, scale_genome=args.scale_genome)
@@ -168,11 +173,11 @@ def main():
         ctr.zero_()
         for rt, ot, nbytes, n in blocks:
             eng.submit_device(rt.data_ptr(), nbytes, ot.data_ptr(), n)
-        reduce_counters(ctr, world)
+        reduce_counters(ctr, 2 if use_dist else 1)
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -186,7 +191,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     kernel_ms, n_launch = eng.kernel_time(reset=True)
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -258,7 +263,7 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     eng.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

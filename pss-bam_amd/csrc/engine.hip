@@ -107,6 +107,8 @@ struct pssbam_engine {
     uint64_t kernel_launches = 0;
     // tuning overrides (environment, for experiments)
     int env_tile_reads = 0, env_grid_mult = 0, env_simple_blocks = 0, env_grid_wgs = 0, env_pieces = 0;
+    uint32_t *d_scratch = nullptr;  // per-workgroup partial tables of the tiled kernel
+    size_t scratch_slots = 0;
     uint32_t dev_pieces = 0;       // prefix pieces sampled from a device-resident block
     uint64_t dev_pieces_avg = 0;   // ... and the mean record size it was sampled at
 };
@@ -216,6 +218,7 @@ extern "C" void pssbam_engine_destroy(pssbam_engine *e) {
     for (hipEvent_t ev : e->event_pool) (void)hipEventDestroy(ev);
     if (e->t_begin) (void)hipEventDestroy(e->t_begin);
     if (e->t_end) (void)hipEventDestroy(e->t_end);
+    if (e->d_scratch) (void)hipFree(e->d_scratch);
     if (e->d_genome) (void)hipFree(e->d_genome);
     if (e->d_ref_info) (void)hipFree(e->d_ref_info);
     if (e->d_rg) (void)hipFree(e->d_rg);
@@ -488,7 +491,17 @@ static int launch_tally(pssbam_engine *e, const uint8_t *d_recs, uint64_t nbytes
         if (rc == PSSBAM_OK) {                                                                     \
             uint32_t grid = (uint32_t)std::min<uint64_t>(n_tiles, (uint64_t)e->n_cu * occ * mult); \
             if (e->env_grid_wgs > 0) grid = (uint32_t)std::min<uint64_t>(n_tiles, (uint64_t)e->env_grid_wgs); \
+            if (e->scratch_slots < grid) {                                                         \
+                HIP_TRY(hipStreamSynchronize(e->stream));                                          \
+                if (e->d_scratch) HIP_TRY(hipFree(e->d_scratch));                                  \
+                e->d_scratch = nullptr;                                                            \
+                e->scratch_slots = std::max<size_t>(grid, (size_t)e->n_cu * 8);                    \
+                HIP_TRY(hipMalloc(&e->d_scratch, e->scratch_slots * SCRATCH_WORDS * sizeof(uint32_t))); \
+            }                                                                                      \
+            P.scratch = e->d_scratch;                                                              \
             hipLaunchKernelGGL((tally_tiled<PSS, KM, LK>), dim3(grid), dim3(TILED_THREADS), lds, e->stream, P); \
+            hipLaunchKernelGGL(reduce_partials, dim3((SCRATCH_WORDS * REDUCE_GROUPS + 255) / 256), dim3(256), 0, e->stream, P, grid, \
+                               (uint32_t)(LK ? 1 : 0));                                            \
         }                                                                                          \
     } while (0)
         if (do_pss && do_kmer) { if (kmer_lds) LAUNCH_TILED(true, true, true); else LAUNCH_TILED(true, true, false); }

@@ -47,6 +47,8 @@ constexpr uint32_t STAGE_SLACK = 64;   // readable bytes behind a staging buffer
 constexpr uint32_t PAIR_LUT_BYTES = 2 * 17 * 8;
 constexpr uint32_t CODE_NONE = 32;     // sheet byte meaning "no count" (33 once the table bit is OR-ed in)
 constexpr uint32_t TABLE_WORDS = 34 * 32;
+// per-workgroup partial results of tally_tiled in global scratch: [table 1024 | k-mer bins 512 | stat deltas 16]
+constexpr uint32_t SCRATCH_KMER = 1024, SCRATCH_DELTA = 1536, SCRATCH_WORDS = 1552;
 constexpr uint32_t REF_LDS_ENTRIES = 64;   // BAM references whose contig info is cached in LDS (+1 for "*")
 
 // ---------------------------------------------------------------------------------------
@@ -564,22 +566,53 @@ __device__ __forceinline__ void tally_tiled_body(const TallyParams &P, const Tal
     }
 
     __syncthreads();
-    if (DO_PSS) {
-        for (uint32_t i = tid; i < 32u * 32u; i += TILED_THREADS) {  // code rows 32,33 are the trash bin
-            const uint32_t v = table[i];
-            const uint32_t row = i & 31u, ct = i >> 5, t = ct & 1u, cell = ct >> 1;
-            if (v && row < n_pos)
-                atomicAdd(&P.counters[(t ? P.off_rev : 0u) + row * 16u + cell], (unsigned long long)v);
-        }
+    // Partial results leave the workgroup as plain coalesced stores into its own scratch slot;
+    // reduce_partials() sums the slots afterwards.  (Flushing with global atomics instead had
+    // ~1000 workgroups queue on the same few hundred counters at the same moment: 6 % of the
+    // kernel's time.)
+    uint32_t *mine = P.scratch + (size_t)blockIdx.x * SCRATCH_WORDS;
+    for (uint32_t i = tid; i < 32u * 32u; i += TILED_THREADS) mine[i] = DO_PSS ? table[i] : 0u;
+    for (uint32_t i = tid; i < 512u; i += TILED_THREADS)
+        mine[SCRATCH_KMER + i] = (LDS_KMER && i < 2u * (1u << (2 * P.K))) ? lds_kmer[i] : 0u;
+    if (tid < 16u) mine[SCRATCH_DELTA + tid] = tid < (uint32_t)ST_USED ? (uint32_t)lds_delta[tid] : 0u;
+}
+
+// Sums the per-workgroup partials of one tally_tiled launch into the u64 counter block.
+// Thread (word w, group g) adds up slots g, g+REDUCE_GROUPS, ... of word w (loads coalesce across
+// w) and contributes one atomic; launched on the same stream right behind the tally kernel.
+constexpr uint32_t REDUCE_GROUPS = 32;
+__global__ void __launch_bounds__(256) reduce_partials(const TallyParams P, uint32_t n_slots, uint32_t lds_kmer_on) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = gid % SCRATCH_WORDS, g = gid / SCRATCH_WORDS;
+    if (g >= REDUCE_GROUPS) return;
+    const bool do_pss = (P.tally_mask & 1u) != 0, do_kmer = (P.tally_mask & 2u) != 0;
+    const uint32_t n_pos = (uint32_t)P.N + 2u;
+    unsigned long long *dst = nullptr;
+    bool is_delta = false;
+    if (i < 1024u) {
+        const uint32_t row = i & 31u, ct = i >> 5, t = ct & 1u, cell = ct >> 1;
+        if (do_pss && row < n_pos) dst = &P.counters[(t ? P.off_rev : 0u) + row * 16u + cell];
+    } else if (i < SCRATCH_DELTA) {
+        const uint32_t k = i - SCRATCH_KMER, nb = do_kmer ? 1u << (2 * P.K) : 0u;
+        if (lds_kmer_on && k < 2u * nb) dst = &P.counters[k < nb ? P.off_k5 + k : P.off_k3 + (k - nb)];
+    } else {
+        const uint32_t k = i - SCRATCH_DELTA;
+        if (k < (uint32_t)ST_USED) { dst = &P.counters[P.off_stats + k]; is_delta = true; }
     }
-    if (LDS_KMER) {
-        const uint32_t nb = 1u << (2 * P.K);
-        for (uint32_t i = tid; i < 2u * nb; i += TILED_THREADS) {
-            const uint32_t v = lds_kmer[i];
-            if (v) atomicAdd(&P.counters[(i < nb ? P.off_k5 + i : P.off_k3 + (i - nb))], (unsigned long long)v);
-        }
+    if (!dst) return;
+    long long sum = 0;
+    const uint32_t *p = P.scratch + i;
+#pragma unroll 8
+    for (uint32_t b = g; b < n_slots; b += REDUCE_GROUPS) {
+        const uint32_t v = p[(size_t)b * SCRATCH_WORDS];
+        sum += is_delta ? (long long)(int32_t)v : (long long)v;
     }
-    flush_events(DO_PSS, DO_KMER, P, lds_delta);
+    if (is_delta && g == 0u) {
+        // every launch credits its record count to the OK slots; the deltas move records elsewhere
+        const uint32_t k = i - SCRATCH_DELTA;
+        if (k == ST_RECORDS || (do_pss && k == ST_PSS_OK) || (do_kmer && k == ST_KMER_OK)) sum += P.n_recs;
+    }
+    if (sum) atomicAdd(dst, (unsigned long long)sum);
 }
 
 template <bool DO_PSS, bool DO_KMER, bool LDS_KMER>
