@@ -107,6 +107,8 @@ struct pssbam_engine {
     uint64_t kernel_launches = 0;
     // tuning overrides (environment, for experiments)
     int env_tile_reads = 0, env_grid_mult = 0, env_simple_blocks = 0, env_grid_wgs = 0, env_pieces = 0;
+    uint32_t prep_lds[8] = {0};     // prep_kernel's memo, by kernel variant
+    int prep_occ[8] = {0};
     uint32_t *d_scratch = nullptr;  // per-workgroup partial tables of the tiled kernel
     size_t scratch_slots = 0;
     uint32_t dev_pieces = 0;       // prefix pieces sampled from a device-resident block
@@ -365,11 +367,19 @@ static int resolve_launch_events(pssbam_engine *e) {
     return PSSBAM_OK;
 }
 
+// dynamic-LDS limit + occupancy of one kernel variant, remembered per (variant, LDS size) so
+// the steady state makes no runtime API calls per launch beyond the launches themselves
 template <class K>
-static int prep_kernel(K kernel, uint32_t lds_bytes, int *occ) {
+static int prep_kernel(pssbam_engine *e, int variant, K kernel, uint32_t lds_bytes, int *occ) {
+    if (e->prep_lds[variant] == lds_bytes && e->prep_occ[variant] > 0) {
+        *occ = e->prep_occ[variant];
+        return PSSBAM_OK;
+    }
     HIP_TRY(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(occ, kernel, TILED_THREADS, lds_bytes));
     if (*occ < 1) return fail(PSSBAM_EHIP, "kernel does not fit a CU with %u bytes of LDS", lds_bytes);
+    e->prep_lds[variant] = lds_bytes;
+    e->prep_occ[variant] = *occ;
     return PSSBAM_OK;
 }
 
@@ -487,7 +497,7 @@ static int launch_tally(pssbam_engine *e, const uint8_t *d_recs, uint64_t nbytes
         const int mult = e->env_grid_mult > 0 ? e->env_grid_mult : 1;
 #define LAUNCH_TILED(PSS, KM, LK)                                                                  \
     do {                                                                                           \
-        rc = prep_kernel(tally_tiled<PSS, KM, LK>, lds, &occ);                                     \
+        rc = prep_kernel(e, (PSS ? 4 : 0) | (KM ? 2 : 0) | (LK ? 1 : 0), tally_tiled<PSS, KM, LK>, lds, &occ); \
         if (rc == PSSBAM_OK) {                                                                     \
             uint32_t grid = (uint32_t)std::min<uint64_t>(n_tiles, (uint64_t)e->n_cu * occ * mult); \
             if (e->env_grid_wgs > 0) grid = (uint32_t)std::min<uint64_t>(n_tiles, (uint64_t)e->env_grid_wgs); \

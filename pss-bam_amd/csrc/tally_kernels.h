@@ -44,9 +44,8 @@ constexpr int TILED_MAX_N = 30;        // N+2 positions per end must fit 32 lane
 constexpr int WIN_DWORDS = 9;          // 32 window bytes + 3 alignment bytes <= 36
 constexpr int KMER_LDS_MAX_K = 4;      // 2 * 4^4 * 4 B = 2 KiB of LDS
 constexpr uint32_t STAGE_SLACK = 64;   // readable bytes behind a staging buffer
-constexpr uint32_t PAIR_LUT_BYTES = 2 * 17 * 8;
-constexpr uint32_t CODE_NONE = 32;     // sheet byte meaning "no count" (33 once the table bit is OR-ed in)
-constexpr uint32_t TABLE_WORDS = 34 * 32;
+constexpr uint32_t CODE_NONE = 32;     // sheet byte meaning "no count"; every code >= 32 is one
+constexpr uint32_t TABLE_WORDS = 64 * 32;  // codes 0..31 = (cell << 1) | table, 32..63 = trash bin
 // per-workgroup partial results of tally_tiled in global scratch: [table 1024 | k-mer bins 512 | stat deltas 16]
 constexpr uint32_t SCRATCH_KMER = 1024, SCRATCH_DELTA = 1536, SCRATCH_WORDS = 1552;
 constexpr uint32_t REF_LDS_ENTRIES = 64;   // BAM references whose contig info is cached in LDS (+1 for "*")
@@ -181,9 +180,8 @@ __global__ void __launch_bounds__(256) tally_simple(const TallyParams P) {
 // separate static object:
 //   stage  (dynamic) : T * P * 16 + STAGE_SLACK          first P pieces of every record of the tile
 //   sheet  : TILED_MAX_T * 64                             code sheet [read][end*32 + position]
-//   table  : 34 * 32 * 4                                  [(cell<<1)|table][row] u32; rows 32,33 = trash bin
+//   table  : 64 * 32 * 4                                  [(cell<<1)|table][row] u32; codes 32..63 = trash bin
 //                                                         for "no count" codes, so the column pass has no branches
-//   lut    : PAIR_LUT_BYTES                               (strand, nibble row, ref code) -> code
 //   ctxf   : 256                                          -U / -D membership flags per stored genome byte
 //   toffs  : 2 * (TILED_MAX_T + 4) * 4                    record offsets of this tile and the next
 //   kmer   : 2 * 4^KMER_LDS_MAX_K * 4                     (LDS_KMER variants only)
@@ -262,7 +260,7 @@ __device__ __attribute__((noinline)) uint32_t tally_overflow_record(const TallyP
 template <bool DO_PSS, bool DO_KMER, bool LDS_KMER>
 __device__ __forceinline__ void tally_tiled_body(const TallyParams &P, const TallyParams *kernarg,
                                                  uint8_t *__restrict__ stage, uint8_t *__restrict__ sheet,
-                                                 uint32_t *__restrict__ table, uint8_t *__restrict__ lut,
+                                                 uint32_t *__restrict__ table,
                                                  uint8_t *__restrict__ ctxf, uint32_t *__restrict__ toffs,
                                                  uint32_t *__restrict__ lds_kmer,
                                                  int32_t *__restrict__ lds_delta, uint4 *__restrict__ refs_lds) {
@@ -276,46 +274,16 @@ __device__ __forceinline__ void tally_tiled_body(const TallyParams &P, const Tal
     const int N = P.N;
     const uint32_t n_pos = (uint32_t)N + 2u;  // rows per table: 2 context + N positions
 
-    // ---- one-time set-up: zero the tables, build the pair LUT ---------------------------------
+    // ---- one-time set-up: zero the tables ---------------------------------------------------------
     for (uint32_t i = tid; i < TABLE_WORDS; i += TILED_THREADS) table[i] = 0u;
     if (LDS_KMER)
         for (uint32_t i = tid; i < 2u * (1u << (2 * P.K)); i += TILED_THREADS) lds_kmer[i] = 0u;
     if (tid < ST_USED) lds_delta[tid] = 0;
-    for (uint32_t i = tid; i < PAIR_LUT_BYTES; i += TILED_THREADS) {
-        // index = strand*136 + row*8 + g ; row 0..15 = read nibble, row 16 = context position
-        // (cell of a context base is the diagonal one, pss-bam.c:172-184); g = min(stored, 4)
-        const uint32_t strand = i / 136u, row = (i % 136u) >> 3, g = i & 7u;
-        const uint32_t rd = row == 16u ? g : nib_code(row);
-        uint32_t v = CODE_NONE;
-        if (g < 4u && rd < 4u) {
-            const uint32_t cell = 4u * rd + g;
-            v = (strand ? 15u - cell : cell) << 1;  // bit 0 (table) is OR-ed in per read
-        }
-        lut[i] = (uint8_t)v;
-    }
-
     if (tid < 256u) ctxf[tid] = (uint8_t)((in_set(P.up_mask, tid) ? 1u : 0u) | (in_set(P.down_mask, tid) ? 2u : 0u));
     // contig info of the first BAM references (all of them for a human-sized header) + the "*" entry
     const uint32_t n_ref_cached = min((uint32_t)P.n_ref, REF_LDS_ENTRIES);
     if (tid < n_ref_cached) refs_lds[tid] = P.ref_info[tid];
     if (tid == n_ref_cached) refs_lds[tid] = P.ref_info[P.n_ref];
-    // bytes of this lane's code-sheet row that lie outside the N+2 live rows stay CODE_NONE:
-    // left end (row = byte) bytes >= n_pos, right end (row = 31 - byte) bytes <= 31 - n_pos
-    uint32_t dead_w[8];
-    {
-        const uint32_t e0 = tid & 1u;
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            uint32_t mk = 0u;
-#pragma unroll
-            for (int b = 0; b < 4; b++) {
-                const uint32_t byte = 4u * k + b, row = e0 ? 31u - byte : byte;
-                if (row >= n_pos) mk |= 0xFFu << (8 * b);
-            }
-            dead_w[k] = mk;
-        }
-    }
-
     const uint32_t n_tiles = (P.n_recs + T - 1u) / T;
     const uint32_t tstride = gridDim.x;
     // software pipeline over this workgroup's tiles k0, k0+stride, ...:
@@ -462,53 +430,67 @@ __device__ __forceinline__ void tally_tiled_body(const TallyParams &P, const Tal
             // this lane's end feeds: left -> fwd table on forward reads, rev table on reverse reads
             const uint32_t tsel = e ^ (pl.rev ? 1u : 0u);
             if (cand && (tsel ? pl.pss_rev : pl.pss_fwd) && !(ablate & 2u)) {
-                uint32_t sw[5];
+                // Four window positions per VALU instruction, no memory lookups: v_perm_b32 with the
+                // DATA as selector is an 8-entry byte table (selectors 0-7 pick a pool byte, 8-11
+                // replicate the sign of pool byte 1/3/5/7, 12 gives 0x00, >= 13 gives 0xFF).
+                //   read base : selector = BAM nibble ^ 4   -> A(1)->5  C(2)->6  G(4)->0  T(8)->12
+                //               pool: [0]=G [5]=A [6]=C, T is the hardware's 0x00, every other nibble
+                //               lands on 0xFF (pool filler, sign replicas of bytes 1,3,5,7, or >= 13);
+                //               value = (3 - idx) << 3  (complemented: T must be 0), A carries 0x80 so
+                //               that selector 10 (nibble 14) replicates a set sign bit
+                //   reference : selector = stored byte with 12 bumped to 13 (12 would read as 0x00);
+                //               pool: [0..3] = (3 - idx) << 1, C and T carry 0x80 (selectors 8, 9)
+                // OR of the two = (15 - cell) << 1, the reverse-strand code; forward-strand lanes XOR
+                // 0x1E to get cell << 1.  Anything invalid is 0xFF and ends, after the final & 0x3F,
+                // on code 33 or 63: rows >= 32 of the count table are the trash bin.
+                uint32_t S[5];
 #pragma unroll
-                for (int k = 0; k < 5; k++) sw[k] = __builtin_amdgcn_alignbyte(rr[k + 1], rr[k], ssh);
+                for (int k = 0; k < 5; k++) S[k] = __builtin_amdgcn_alignbyte(rr[k + 1], rr[k], ssh);
+                // stream byte i holds positions 2i (high nibble), 2i+1 (low nibble) when n0 is even;
+                // when n0 is odd position 2i is the LOW nibble of byte i and 2i+1 the HIGH nibble of
+                // byte i+1
+                const bool odd = (n0 & 1) != 0;
+                const uint32_t M = 0x0F0F0F0Fu;
+                uint32_t nb[8];
 #pragma unroll
-                for (int k = 0; k < 5; k++)  // high nibble first -> nibble q at bits 4q
-                    sw[k] = ((sw[k] & 0x0F0F0F0Fu) << 4) | ((sw[k] >> 4) & 0x0F0F0F0Fu);
-                if (n0 & 1) {
-#pragma unroll
-                    for (int k = 0; k < 4; k++) sw[k] = (sw[k] >> 4) | (sw[k + 1] << 28);
+                for (int m = 0; m < 4; m++) {
+                    const uint32_t S1 = __builtin_amdgcn_alignbyte(S[m + 1], S[m], 1);
+                    const uint32_t A = odd ? S1 : S[m];
+                    const uint32_t hiA = (A >> 4) & M, loS = S[m] & M;
+                    const uint32_t E = odd ? loS : hiA, O = odd ? hiA : loS;  // even / odd positions
+                    nb[2 * m] = __builtin_amdgcn_perm(O, E, 0x05010400u);      // positions 8m .. 8m+3
+                    nb[2 * m + 1] = __builtin_amdgcn_perm(O, E, 0x07030602u);  // positions 8m+4 .. 8m+7
                 }
-                // bases at or beyond l_seq do not exist (precondition P3): blank them
+                const uint32_t sx = pl.rev ? 0u : 0x1E1E1E1Eu;
+                const uint32_t tsel4 = tsel * 0x01010101u;
+                uint32_t Rl[8], Gl[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    Rl[k] = __builtin_amdgcn_perm(0xFF1098FFu, 0xFFFFFF08u, nb[k] ^ 0x04040404u);
+                    Gl[k] = __builtin_amdgcn_perm(0xFFFFFFFFu, 0x80028406u, gw[k] | ((gw[k] >> 3) & 0x01010101u));
+                }
+                // bases at or beyond l_seq do not exist (precondition P3): blank them.  Rare (reads
+                // shorter than the window), so the whole wave skips it when no lane needs it.
                 const int32_t have_s = (int32_t)h.l_seq - n0;
                 const uint32_t have = have_s <= 0 ? 0u : have_s >= 32 ? 32u : (uint32_t)have_s;
+                if (__any(have < (e ? 30u : 32u))) {
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const uint32_t lo = 8u * k;
-                    const uint32_t keep = have >= lo + 8u ? 0xFFFFFFFFu : have > lo ? ((1u << (4u * (have - lo))) - 1u) : 0u;
-                    sw[k] &= keep;
-                }
-                // context bytes carry no read base: give them the nibble of their own reference
-                // base, the LUT then yields the diagonal cell (pss-bam.c:172-184).  Left: bytes 0,1;
-                // right: bytes 30,31.
-                {
-                    const uint32_t ga_ = min((e ? gw[7] >> 16 : gw[0]) & 0xFFu, 3u);
-                    const uint32_t gb_ = min((e ? gw[7] >> 24 : gw[0] >> 8) & 0xFFu, 3u);
-                    const uint32_t two = (1u << ga_) | ((1u << gb_) << 4);  // nibbles of the two context bytes
-                    if (e == 0u) sw[0] = (sw[0] & ~0xFFu) | two;                     // stream nibbles 0,1
-                    else sw[3] = (sw[3] & 0x00FFFFFFu) | (two << 24);               // stream nibbles 30,31
-                }
-                const uint8_t *lut_s = lut + (pl.rev ? 136u : 0u);
-                const uint32_t tsel4 = tsel * 0x01010101u;  // CODE_NONE | 1 is a trash row too
-#pragma unroll
-                for (int half = 0; half < 2; half++) {  // branch-free: 16 independent LUT reads in flight
-                    uint32_t cb[16];
-#pragma unroll
-                    for (int i = 0; i < 16; i++) {
-                        const int b = 16 * half + i;
-                        const uint32_t g = min((gw[b >> 2] >> (8 * (b & 3))) & 0xFFu, 4u);
-                        const uint32_t nib = (sw[b >> 3] >> (4 * (b & 7))) & 0xFu;
-                        cb[i] = lut_s[nib * 8u + g];
+                    for (int k = 0; k < 8; k++) {
+                        const uint32_t lo = 4u * k;
+                        const uint32_t keep = have >= lo + 4u ? 0xFFFFFFFFu : have > lo ? ((1u << (8u * (have - lo))) - 1u) : 0u;
+                        Rl[k] |= ~keep;
                     }
-#pragma unroll
-                    for (int k = 0; k < 4; k++)
-                        code_w[4 * half + k] = (((cb[4 * k] | (cb[4 * k + 1] << 8) | (cb[4 * k + 2] << 16) |
-                                                  (cb[4 * k + 3] << 24)) | tsel4) & ~dead_w[4 * half + k]) |
-                                               ((CODE_NONE * 0x01010101u) & dead_w[4 * half + k]);
                 }
+                // context positions carry no read base: their cell is the diagonal one of their own
+                // reference base (pss-bam.c:172-184).  Left: bytes 0,1; right: bytes 30,31.
+                {
+                    const uint32_t d0 = (Gl[0] & 0x06060606u) << 2, d7 = (Gl[7] & 0x06060606u) << 2;
+                    const uint32_t m0 = e ? 0u : 0x0000FFFFu, m7 = e ? 0xFFFF0000u : 0u;
+                    Rl[0] = (Rl[0] & ~m0) | (d0 & m0);
+                    Rl[7] = (Rl[7] & ~m7) | (d7 & m7);
+                }
+#pragma unroll
+                for (int k = 0; k < 8; k++) code_w[k] = ((Rl[k] | Gl[k] | tsel4) ^ sx) & 0x3F3F3F3Fu;
             }
             bool kmer_ok = true;
             if (kmer_try) {
@@ -620,7 +602,6 @@ __global__ void __launch_bounds__(TILED_THREADS) tally_tiled(const TallyParams P
     extern __shared__ __attribute__((aligned(16))) uint8_t stage[];
     __shared__ __attribute__((aligned(16))) uint8_t sheet[TILED_MAX_T * 64u];
     __shared__ uint32_t table[TABLE_WORDS];
-    __shared__ __attribute__((aligned(16))) uint8_t lut[PAIR_LUT_BYTES];
     __shared__ uint8_t ctxf[256];
     __shared__ uint32_t toffs[2u * (TILED_MAX_T + 4u)];
     __shared__ uint32_t lds_kmer[LDS_KMER ? 2u * (1u << (2 * KMER_LDS_MAX_K)) : 1u];
@@ -628,7 +609,7 @@ __global__ void __launch_bounds__(TILED_THREADS) tally_tiled(const TallyParams P
     __shared__ uint4 refs_lds[REF_LDS_ENTRIES + 1];
     // the kernel's single argument, as it lies in the kernarg segment (for the out-of-line path)
     const TallyParams *kernarg = (const TallyParams *)__builtin_amdgcn_kernarg_segment_ptr();
-    tally_tiled_body<DO_PSS, DO_KMER, LDS_KMER>(P, kernarg, stage, sheet, table, lut, ctxf, toffs, lds_kmer, lds_delta, refs_lds);
+    tally_tiled_body<DO_PSS, DO_KMER, LDS_KMER>(P, kernarg, stage, sheet, table, ctxf, toffs, lds_kmer, lds_delta, refs_lds);
 }
 
 // genome-kmer-count (genome-kmer-count.c:69-79): every k-mer start of the device genome.  Each

@@ -1,14 +1,19 @@
 /*
  * pss-bam_amd/host/bam_reader.c -- multi-threaded BGZF inflate + BAM framing.
  *
- * Pipeline per batch:
- *   1. read() a slab of the compressed file, find the BGZF block boundaries by walking the
- *      18-byte headers (BSIZE) and pick up each block's ISIZE from its trailer;
- *   2. prefix-sum the ISIZEs: every block now knows where its payload goes in the batch buffer;
- *   3. worker threads pull block indices from a shared counter and inflate (raw deflate,
- *      zlib) directly into place, checking CRC32 and ISIZE;
- *   4. follow the block_size chain over the inflated bytes to index whole records; the
- *      trailing partial record is carried to the front of the next batch.
+ * The compressed file is mmap()ed; one producer thread turns it into batches of whole raw
+ * alignment records, ahead of the caller, through two batch slots:
+ *   1. walk the 18-byte BGZF headers (BSIZE) from the current file offset and pick up each
+ *      block's ISIZE from its trailer, until the slot is full; a running sum of the ISIZEs
+ *      tells every block where its payload goes in the slot;
+ *   2. a persistent pool of worker threads pulls block indices from a shared counter and
+ *      inflates (raw deflate, zlib) straight from the mapping into place, checking CRC32 and
+ *      ISIZE -- the page faults of the mapping are taken by the workers, in parallel;
+ *   3. follow the block_size chain over the inflated bytes to index whole records; the
+ *      trailing partial record is carried to the front of the next slot.
+ * bam_reader_next() only hands a finished slot over and gives the previous one back, so the
+ * caller's work on batch i (H2D copy + kernel) overlaps the inflate of batch i+1.
+ * Inputs that cannot be mapped (pipes) are read into memory first.
  * Format references: SAM/BAM specification sections 4.1 (BGZF) and 4.2 (BAM).
  */
 #include "bam_reader.h"
@@ -17,62 +22,77 @@
 #include <fcntl.h>
 #include <pthread.h>
 #include <stdarg.h>
+#include <stdatomic.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <time.h>
 #include <unistd.h>
 #include <zlib.h>
 
 #define BGZF_MAX_BLOCK 65536u
 #define UPAD 4096u /* slack behind each batch buffer (device over-reads, page alignment) */
+#define MAX_WORKERS 64
+#define GRAB 8     /* blocks a worker takes per visit to the shared counter */
 
 typedef struct {
-    size_t coff;     /* offset of the block in the compressed slab */
-    uint32_t clen;   /* whole block length (BSIZE + 1)             */
+    size_t coff;     /* offset of the block in the compressed input */
+    uint32_t clen;   /* whole block length (BSIZE + 1)              */
     uint32_t xlen;
     uint32_t isize;
-    size_t uoff;     /* destination offset in the batch buffer     */
+    size_t uoff;     /* destination offset in the batch slot        */
 } blk_t;
+
+enum { SLOT_FREE = 0, SLOT_READY = 1 };
+
+typedef struct {
+    uint8_t *buf;      /* ucap + UPAD bytes                                               */
+    size_t start;      /* first record byte (behind the BAM header in the first batch)    */
+    size_t rec_end;    /* end of the last whole record                                    */
+    uint32_t *offs;    /* n_recs + 1 offsets relative to `start`                          */
+    size_t offs_cap, n_recs;
+    int state;         /* guarded by bam_reader.mu                                        */
+    int eof;           /* no records: the input is exhausted                              */
+    int rc;            /* -1: the fill failed, bam_reader.err says why                    */
+} slot_t;
 
 struct bam_reader {
     int fd;
-    int n_threads;
-    /* compressed slab */
-    uint8_t *cbuf;
-    size_t ccap, clen, cpos; /* valid bytes [cpos, clen) */
-    int file_eof;
-    /* inflated batches: two buffers (one allocation).  The caller works on `cur` while a
-     * background thread already inflates the following batch into the other one. */
-    uint8_t *ubase;    /* the allocation: 2 * (ucap + UPAD) bytes                          */
-    uint8_t *ubuf;     /* = buffer `cur`                                                  */
-    int cur;
+    /* compressed input */
+    const uint8_t *cdata;
+    size_t clen, cpos;
+    int mapped;        /* cdata is an mmap (else malloc) */
+    /* batch slots, one allocation so a caller can page-lock it in one go */
+    uint8_t *ubase;
     size_t ucap;
-    size_t ulen;       /* valid inflated bytes of buffer `cur`                            */
-    size_t upos;       /* first byte of it not yet handed out                             */
-    /* background fill of the other buffer */
-    pthread_t bg_thread;
-    int bg_running;
-    int bg_rc;
-    size_t bg_ulen;    /* valid bytes the fill left in the other buffer                   */
-    const uint8_t *bg_carry;
-    size_t bg_carry_len;
-    int bg_pending;    /* a batch was handed out and its successor is being (was) prefetched */
-    /* block table of the current batch */
+    slot_t slot[2];
+    int take;          /* slot the next bam_reader_next() returns   */
+    int held;          /* slot the caller is working on, or -1      */
+    /* producer */
+    pthread_t producer;
+    int producer_started;
+    int stop;          /* guarded by mu */
+    int header_state;  /* 0 pending, 1 parsed, -1 failed; guarded by mu */
+    pthread_mutex_t mu;
+    pthread_cond_t cv;
     blk_t *blk;
     size_t n_blk, blk_cap;
-    /* record index of the current batch */
-    uint32_t *offs;
-    size_t offs_cap;
     bam_header hdr;
-    int header_done;
     char err[256];
     double inflate_s;
-    /* worker coordination */
-    uint8_t *ubuf_fill; /* buffer the inflate workers write into */
-    size_t next_blk;
-    pthread_mutex_t mu;
-    int worker_failed;
+    /* inflate workers */
+    int n_threads;     /* pool size; <= 1 means inflate in the producer itself */
+    pthread_t worker[MAX_WORKERS];
+    int n_workers;
+    pthread_mutex_t job_mu;
+    pthread_cond_t job_cv, done_cv;
+    unsigned long job_gen;
+    int job_active, job_quit;
+    uint8_t *job_dst;
+    atomic_size_t job_next;
+    atomic_int job_failed;
 };
 
 static void set_err(bam_reader *r, const char *fmt, ...)
@@ -93,28 +113,7 @@ static double now_s(void)
 static uint32_t le16(const uint8_t *p) { return p[0] | ((uint32_t)p[1] << 8); }
 static uint32_t le32(const uint8_t *p) { return p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
 
-/* refill the compressed slab: keep [cpos, clen), append from the file */
-static int slab_fill(bam_reader *r)
-{
-    if (r->cpos > 0) {
-        memmove(r->cbuf, r->cbuf + r->cpos, r->clen - r->cpos);
-        r->clen -= r->cpos;
-        r->cpos = 0;
-    }
-    while (!r->file_eof && r->clen < r->ccap) {
-        ssize_t n = read(r->fd, r->cbuf + r->clen, r->ccap - r->clen);
-        if (n < 0) {
-            if (errno == EINTR) continue;
-            set_err(r, "read failed: %s", strerror(errno));
-            return -1;
-        }
-        if (n == 0) { r->file_eof = 1; break; }
-        r->clen += (size_t)n;
-    }
-    return 0;
-}
-
-/* parses one BGZF header at p (avail bytes); 0 = need more bytes, -1 = not BGZF, else block length */
+/* parses one BGZF header at p (avail bytes); 0 = cut short, -1 = not BGZF, else block length */
 static long bgzf_block_len(const uint8_t *p, size_t avail, uint32_t *xlen_out)
 {
     uint32_t xlen, o;
@@ -133,197 +132,269 @@ static long bgzf_block_len(const uint8_t *p, size_t avail, uint32_t *xlen_out)
     return -1;
 }
 
-static void *inflate_worker(void *arg)
+/* ---- inflate workers ------------------------------------------------------------------------ */
+
+/* inflates blocks of the current job until the shared counter runs past the table */
+static void inflate_blocks(bam_reader *r, z_stream *zs)
 {
-    bam_reader *r = (bam_reader *)arg;
-    z_stream zs;
-    memset(&zs, 0, sizeof zs);
-    if (inflateInit2(&zs, -15) != Z_OK) {
-        pthread_mutex_lock(&r->mu);
-        r->worker_failed = 1;
-        pthread_mutex_unlock(&r->mu);
-        return NULL;
-    }
     for (;;) {
-        size_t i;
-        const blk_t *b;
-        const uint8_t *src;
-        pthread_mutex_lock(&r->mu);
-        i = r->next_blk;
-        r->next_blk += 8; /* a few blocks per grab keeps the lock cold */
-        pthread_mutex_unlock(&r->mu);
+        const size_t i = atomic_fetch_add(&r->job_next, GRAB);
         if (i >= r->n_blk) break;
-        for (size_t k = i; k < i + 8 && k < r->n_blk; k++) {
-            b = &r->blk[k];
+        for (size_t k = i; k < i + GRAB && k < r->n_blk; k++) {
+            const blk_t *b = &r->blk[k];
+            const uint8_t *src = r->cdata + b->coff;
+            uint8_t *dst = r->job_dst + b->uoff;
             if (b->isize == 0) continue;
-            src = r->cbuf + b->coff;
-            inflateReset(&zs);
-            zs.next_in = (Bytef *)(src + 12 + b->xlen);
-            zs.avail_in = b->clen - 12 - b->xlen - 8;
-            zs.next_out = r->ubuf_fill + b->uoff;
-            zs.avail_out = b->isize;
-            if (inflate(&zs, Z_FINISH) != Z_STREAM_END || zs.avail_out != 0 ||
-                (uint32_t)crc32(crc32(0L, Z_NULL, 0), r->ubuf_fill + b->uoff, b->isize) != le32(src + b->clen - 8)) {
-                pthread_mutex_lock(&r->mu);
-                r->worker_failed = 1;
-                pthread_mutex_unlock(&r->mu);
-            }
+            inflateReset(zs);
+            zs->next_in = (Bytef *)(src + 12 + b->xlen);
+            zs->avail_in = b->clen - 12 - b->xlen - 8;
+            zs->next_out = dst;
+            zs->avail_out = b->isize;
+            if (inflate(zs, Z_FINISH) != Z_STREAM_END || zs->avail_out != 0 ||
+                (uint32_t)crc32(crc32(0L, Z_NULL, 0), dst, b->isize) != le32(src + b->clen - 8))
+                atomic_store(&r->job_failed, 1);
         }
     }
-    inflateEnd(&zs);
+}
+
+static void *worker_main(void *arg)
+{
+    bam_reader *r = (bam_reader *)arg;
+    unsigned long seen = 0;
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    const int zok = inflateInit2(&zs, -15) == Z_OK;
+    for (;;) {
+        pthread_mutex_lock(&r->job_mu);
+        while (r->job_gen == seen && !r->job_quit) pthread_cond_wait(&r->job_cv, &r->job_mu);
+        seen = r->job_gen;
+        const int quit = r->job_quit;
+        pthread_mutex_unlock(&r->job_mu);
+        if (quit) break;
+        if (zok) inflate_blocks(r, &zs);
+        pthread_mutex_lock(&r->job_mu);
+        if (--r->job_active == 0) pthread_cond_signal(&r->done_cv);
+        pthread_mutex_unlock(&r->job_mu);
+    }
+    if (zok) inflateEnd(&zs);
     return NULL;
 }
 
-/* Fills batch buffer `dst` with [carry bytes | as many whole inflated BGZF blocks as fit];
- * *len_out = valid bytes.  The worker threads write into `dst` through r->ubuf_fill.
- * Returns 0 ok / -1 error. */
-static int fill_buffer(bam_reader *r, uint8_t *dst, const uint8_t *carry, size_t carry_len, size_t *len_out)
+/* inflates r->blk[0 .. n_blk) into dst; 0 ok / -1 error */
+static int run_inflate(bam_reader *r, uint8_t *dst)
 {
-    double t0;
+    const double t0 = now_s();
+    r->job_dst = dst;
+    atomic_store(&r->job_next, 0);
+    atomic_store(&r->job_failed, 0);
+    if (r->n_workers > 0) {
+        pthread_mutex_lock(&r->job_mu);
+        r->job_gen++;
+        r->job_active = r->n_workers;
+        pthread_cond_broadcast(&r->job_cv);
+        pthread_mutex_unlock(&r->job_mu);
+    }
+    { /* the producer lends a hand (and is the only inflater when there is no pool) */
+        z_stream zs;
+        memset(&zs, 0, sizeof zs);
+        if (inflateInit2(&zs, -15) == Z_OK) {
+            inflate_blocks(r, &zs);
+            inflateEnd(&zs);
+        } else if (r->n_workers == 0) {
+            atomic_store(&r->job_failed, 1);
+        }
+    }
+    if (r->n_workers > 0) {
+        pthread_mutex_lock(&r->job_mu);
+        while (r->job_active) pthread_cond_wait(&r->done_cv, &r->job_mu);
+        pthread_mutex_unlock(&r->job_mu);
+    }
+    r->inflate_s += now_s() - t0;
+    if (atomic_load(&r->job_failed)) { set_err(r, "BGZF inflate / CRC check failed"); return -1; }
+    return 0;
+}
+
+/* ---- producer ------------------------------------------------------------------------------- */
+
+/* Fills `dst` with [carry bytes | as many whole inflated BGZF blocks as fit]; *len_out = valid
+ * bytes, *full = stopped because the next block does not fit (not because the input ended). */
+static int fill_buffer(bam_reader *r, uint8_t *dst, const uint8_t *carry, size_t carry_len, size_t *len_out, int *full)
+{
     if (carry_len) memmove(dst, carry, carry_len);
     r->n_blk = 0;
+    *full = 0;
     size_t uoff = carry_len;
-    for (;;) {
-        if (r->clen - r->cpos < BGZF_MAX_BLOCK && !r->file_eof) {
-            /* the block table refers to slab offsets: stop here if blocks are already queued */
-            if (r->n_blk) break;
-            if (slab_fill(r)) return -1;
-        }
-        if (r->cpos >= r->clen) break; /* end of file */
+    while (r->cpos < r->clen) {
         uint32_t xlen = 0;
-        long bl = bgzf_block_len(r->cbuf + r->cpos, r->clen - r->cpos, &xlen);
-        if (bl < 0) { set_err(r, "not a BGZF block at compressed offset (corrupt or not a BAM file)"); return -1; }
-        if (bl == 0 || (size_t)bl > r->clen - r->cpos) {
-            if (r->file_eof) { set_err(r, "truncated BGZF block at end of file"); return -1; }
-            if (r->n_blk) break;
-            if (slab_fill(r)) return -1;
-            continue;
-        }
+        const size_t avail = r->clen - r->cpos;
+        const long bl = bgzf_block_len(r->cdata + r->cpos, avail, &xlen);
+        if (bl < 0) { set_err(r, "not a BGZF block at offset %zu (corrupt or not a BAM file)", r->cpos); return -1; }
+        if (bl == 0 || (size_t)bl > avail) { set_err(r, "truncated BGZF block at end of file"); return -1; }
         if ((size_t)bl < 12u + xlen + 8u) { set_err(r, "BGZF block shorter than its own header"); return -1; }
-        uint32_t isize = le32(r->cbuf + r->cpos + bl - 4);
+        const uint32_t isize = le32(r->cdata + r->cpos + bl - 4);
         if (isize > BGZF_MAX_BLOCK) { set_err(r, "BGZF ISIZE %u exceeds 64 KiB", isize); return -1; }
-        if (uoff + isize > r->ucap) break; /* batch buffer full */
+        if (uoff + isize > r->ucap) { *full = 1; break; }
         if (r->n_blk == r->blk_cap) {
-            r->blk_cap = r->blk_cap ? r->blk_cap * 2 : 8192;
-            r->blk = (blk_t *)realloc(r->blk, r->blk_cap * sizeof(blk_t));
+            const size_t cap = r->blk_cap ? r->blk_cap * 2 : 8192;
+            blk_t *nb = (blk_t *)realloc(r->blk, cap * sizeof(blk_t));
+            if (!nb) { set_err(r, "out of memory"); return -1; }
+            r->blk = nb;
+            r->blk_cap = cap;
         }
         r->blk[r->n_blk++] = (blk_t){r->cpos, (uint32_t)bl, xlen, isize, uoff};
         uoff += isize;
         r->cpos += (size_t)bl;
     }
     *len_out = uoff;
-    if (r->n_blk == 0) return 0;
-    t0 = now_s();
-    r->next_blk = 0;
-    r->worker_failed = 0;
-    r->ubuf_fill = dst;
-    {
-        int nt = r->n_threads;
-        if ((size_t)nt > (r->n_blk + 7) / 8) nt = (int)((r->n_blk + 7) / 8);
-        if (nt <= 1) {
-            inflate_worker(r);
-        } else {
-            pthread_t th[64];
-            int started = 0;
-            for (int t = 0; t < nt && t < 64; t++)
-                if (pthread_create(&th[started], NULL, inflate_worker, r) == 0) started++;
-            if (started == 0) inflate_worker(r);
-            for (int t = 0; t < started; t++) pthread_join(th[t], NULL);
-        }
-    }
-    r->inflate_s += now_s() - t0;
-    if (r->worker_failed) { set_err(r, "BGZF inflate / CRC check failed"); return -1; }
-    return 0;
+    return r->n_blk ? run_inflate(r, dst) : 0;
 }
 
-/* synchronous refill of the current buffer: keeps its unconsumed tail, appends more blocks */
-static int batch_fill(bam_reader *r)
+/* BAM header at p[0 .. len); 0 ok (*end_out = first record byte) / -1 error */
+static int parse_header(bam_reader *r, const uint8_t *p, size_t len, int input_done, size_t *end_out)
 {
-    size_t len = 0;
-    if (fill_buffer(r, r->ubuf, r->ubuf + r->upos, r->ulen - r->upos, &len)) return -1;
-    r->ulen = len;
-    r->upos = 0;
-    return 0;
-}
-
-/* background: the batch after the current one goes into the other buffer */
-static void *bg_fill_main(void *arg)
-{
-    bam_reader *r = (bam_reader *)arg;
-    uint8_t *dst = r->ubase + (size_t)(r->cur ^ 1) * (r->ucap + UPAD);
-    r->bg_rc = fill_buffer(r, dst, r->bg_carry, r->bg_carry_len, &r->bg_ulen);
-    return NULL;
-}
-
-static void bg_start(bam_reader *r, const uint8_t *carry, size_t carry_len)
-{
-    r->bg_carry = carry;
-    r->bg_carry_len = carry_len;
-    r->bg_rc = 0;
-    r->bg_running = pthread_create(&r->bg_thread, NULL, bg_fill_main, r) == 0;
-    if (!r->bg_running) bg_fill_main(r); /* no thread: do it now */
-}
-
-/* waits for the background fill and makes its buffer the current one; 0 ok / -1 error */
-static int bg_take(bam_reader *r)
-{
-    if (r->bg_running) {
-        pthread_join(r->bg_thread, NULL);
-        r->bg_running = 0;
-    }
-    if (r->bg_rc) return -1;
-    r->cur ^= 1;
-    r->ubuf = r->ubase + (size_t)r->cur * (r->ucap + UPAD);
-    r->ulen = r->bg_ulen;
-    r->upos = 0;
-    return 0;
-}
-
-/* makes at least `need` inflated bytes available at upos (for the header); 0 ok, 1 EOF first, -1 error */
-static int need_bytes(bam_reader *r, size_t need)
-{
-    while (r->ulen - r->upos < need) {
-        size_t before = r->ulen - r->upos;
-        if (need > r->ucap) { set_err(r, "BAM header larger than the batch buffer"); return -1; }
-        if (batch_fill(r)) return -1;
-        if (r->ulen - r->upos == before) return 1;
-    }
-    return 0;
-}
-
-static int parse_header(bam_reader *r)
-{
-    int rc;
-    if ((rc = need_bytes(r, 12))) { if (rc > 0) set_err(r, "file too short for a BAM header"); return -1; }
-    const uint8_t *p = r->ubuf + r->upos;
+    const char *cut = input_done ? "truncated BAM header" : "BAM header larger than the batch buffer";
+    if (len < 12) { set_err(r, input_done ? "file too short for a BAM header" : cut); return -1; }
     if (memcmp(p, "BAM\1", 4) != 0) { set_err(r, "BAM magic not found"); return -1; }
-    uint32_t l_text = le32(p + 4);
-    if ((rc = need_bytes(r, 12 + (size_t)l_text))) { if (rc > 0) set_err(r, "truncated BAM header text"); return -1; }
-    p = r->ubuf + r->upos;
+    const uint32_t l_text = le32(p + 4);
+    if (len < 12 + (size_t)l_text) { set_err(r, "%s", cut); return -1; }
     r->hdr.l_text = l_text;
     r->hdr.text = (char *)malloc((size_t)l_text + 1);
+    if (!r->hdr.text) { set_err(r, "out of memory"); return -1; }
     memcpy(r->hdr.text, p + 8, l_text);
     r->hdr.text[l_text] = '\0';
-    int32_t n_ref = (int32_t)le32(p + 8 + l_text);
+    const int32_t n_ref = (int32_t)le32(p + 8 + l_text);
     if (n_ref < 0) { set_err(r, "negative reference count"); return -1; }
-    r->hdr.n_ref = n_ref;
     r->hdr.ref_name = (char **)calloc((size_t)n_ref + 1, sizeof(char *));
     r->hdr.ref_len = (uint32_t *)calloc((size_t)n_ref + 1, sizeof(uint32_t));
+    if (!r->hdr.ref_name || !r->hdr.ref_len) { set_err(r, "out of memory"); return -1; }
     size_t o = 12 + (size_t)l_text;
     for (int32_t i = 0; i < n_ref; i++) {
-        if ((rc = need_bytes(r, o + 4))) { if (rc > 0) set_err(r, "truncated reference list"); return -1; }
-        uint32_t l_name = le32(r->ubuf + r->upos + o);
+        if (len < o + 4) { set_err(r, "%s", cut); return -1; }
+        const uint32_t l_name = le32(p + o);
         if (l_name == 0 || l_name > (1u << 20)) { set_err(r, "bad reference name length"); return -1; }
-        if ((rc = need_bytes(r, o + 8 + l_name))) { if (rc > 0) set_err(r, "truncated reference list"); return -1; }
-        p = r->ubuf + r->upos;
+        if (len < o + 8 + l_name) { set_err(r, "%s", cut); return -1; }
         r->hdr.ref_name[i] = (char *)malloc(l_name);
+        if (!r->hdr.ref_name[i]) { set_err(r, "out of memory"); return -1; }
         memcpy(r->hdr.ref_name[i], p + o + 4, l_name);
         r->hdr.ref_name[i][l_name - 1] = '\0';
         r->hdr.ref_len[i] = le32(p + o + 4 + l_name);
+        r->hdr.n_ref = i + 1;
         o += 8 + l_name;
     }
-    r->upos += o;
-    r->header_done = 1;
+    *end_out = o;
+    return 0;
+}
+
+/* indexes the whole records of s->buf[s->start .. len); 0 ok / -1 error */
+static int index_slot(bam_reader *r, slot_t *s, size_t len)
+{
+    size_t o = s->start, n = 0;
+    while (o + 4 <= len) {
+        const uint32_t bs = le32(s->buf + o);
+        if (bs < 32) { set_err(r, "alignment record with block_size %u < 32", bs); return -1; }
+        if (o + 4 + (size_t)bs > len) break;
+        if (n + 2 > s->offs_cap) {
+            const size_t cap = s->offs_cap ? s->offs_cap * 2 : (1u << 20);
+            uint32_t *no = (uint32_t *)realloc(s->offs, cap * sizeof(uint32_t));
+            if (!no) { set_err(r, "out of memory"); return -1; }
+            s->offs = no;
+            s->offs_cap = cap;
+        }
+        s->offs[n++] = (uint32_t)(o - s->start);
+        o += 4 + (size_t)bs;
+    }
+    if (n) s->offs[n] = (uint32_t)(o - s->start);
+    s->n_recs = n;
+    s->rec_end = o;
+    return 0;
+}
+
+static void *producer_main(void *arg)
+{
+    bam_reader *r = (bam_reader *)arg;
+    const uint8_t *carry = NULL;
+    size_t carry_len = 0;
+    int first = 1;
+    for (int w = 0;; w ^= 1) {
+        slot_t *s = &r->slot[w];
+        pthread_mutex_lock(&r->mu);
+        while (s->state != SLOT_FREE && !r->stop) pthread_cond_wait(&r->cv, &r->mu);
+        const int stop = r->stop;
+        pthread_mutex_unlock(&r->mu);
+        if (stop) break;
+
+        size_t len = 0;
+        int full = 0;
+        int rc = fill_buffer(r, s->buf, carry, carry_len, &len, &full);
+        s->start = 0;
+        if (rc == 0 && first) rc = parse_header(r, s->buf, len, !full, &s->start);
+        if (rc == 0) rc = index_slot(r, s, len);
+        if (rc == 0 && s->n_recs == 0 && len > s->start) {
+            /* bytes in hand but not one whole record */
+            if (full) {
+                set_err(r, "alignment record of %u bytes exceeds the batch buffer", len - s->start >= 4 ? le32(s->buf + s->start) : 0u);
+            } else {
+                set_err(r, "truncated alignment record at end of file");
+            }
+            rc = -1;
+        }
+        s->rc = rc;
+        s->eof = rc == 0 && s->n_recs == 0;
+        carry = s->buf + s->rec_end;
+        carry_len = rc == 0 ? len - s->rec_end : 0;
+
+        pthread_mutex_lock(&r->mu);
+        if (first) r->header_state = (rc == 0 || s->start) ? 1 : -1;
+        s->state = SLOT_READY;
+        pthread_cond_broadcast(&r->cv);
+        pthread_mutex_unlock(&r->mu);
+        first = 0;
+        if (rc || s->eof) break; /* the last slot stays READY: every later call sees it again */
+    }
+    return NULL;
+}
+
+/* ---- API ------------------------------------------------------------------------------------ */
+
+/* maps the file, or reads it into memory when it cannot be mapped (pipe, character device) */
+static int load_input(bam_reader *r, const char *path)
+{
+    struct stat st;
+    r->fd = open(path, O_RDONLY);
+    if (r->fd < 0) { set_err(r, "cannot open %s: %s", path, strerror(errno)); return -1; }
+    if (fstat(r->fd, &st) == 0 && S_ISREG(st.st_mode)) {
+        if (st.st_size == 0) { r->cdata = NULL; r->clen = 0; return 0; }
+        void *m = mmap(NULL, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, r->fd, 0);
+        if (m != MAP_FAILED) {
+            (void)madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
+            r->cdata = (const uint8_t *)m;
+            r->clen = (size_t)st.st_size;
+            r->mapped = 1;
+            return 0;
+        }
+    }
+    size_t cap = (size_t)64 << 20, len = 0;
+    uint8_t *buf = (uint8_t *)malloc(cap);
+    while (buf) {
+        if (len == cap) {
+            uint8_t *nb = (uint8_t *)realloc(buf, cap * 2);
+            if (!nb) { free(buf); buf = NULL; break; }
+            buf = nb;
+            cap *= 2;
+        }
+        ssize_t n = read(r->fd, buf + len, cap - len);
+        if (n < 0) {
+            if (errno == EINTR) continue;
+            set_err(r, "%s: read failed: %s", path, strerror(errno));
+            free(buf);
+            return -1;
+        }
+        if (n == 0) break;
+        len += (size_t)n;
+    }
+    if (!buf) { set_err(r, "out of memory"); return -1; }
+    r->cdata = buf;
+    r->clen = len;
     return 0;
 }
 
@@ -331,42 +402,52 @@ bam_reader *bam_reader_open(const char *path, int n_threads, size_t batch_bytes,
 {
     bam_reader *r = (bam_reader *)calloc(1, sizeof *r);
     if (!r) return NULL;
-    r->fd = open(path, O_RDONLY);
-    if (r->fd < 0) {
-        if (err) snprintf(err, errlen, "cannot open %s: %s", path, strerror(errno));
-        free(r);
-        return NULL;
-    }
-#ifdef POSIX_FADV_SEQUENTIAL
-    (void)posix_fadvise(r->fd, 0, 0, POSIX_FADV_SEQUENTIAL);
-#endif
+    r->fd = -1;
+    r->held = -1;
+    pthread_mutex_init(&r->mu, NULL);
+    pthread_cond_init(&r->cv, NULL);
+    pthread_mutex_init(&r->job_mu, NULL);
+    pthread_cond_init(&r->job_cv, NULL);
+    pthread_cond_init(&r->done_cv, NULL);
+    if (load_input(r, path)) goto fail;
+
     if (n_threads <= 0) {
         long n = sysconf(_SC_NPROCESSORS_ONLN);
         n_threads = n > 32 ? 32 : (n < 1 ? 1 : (int)n);
     }
+    if (n_threads > MAX_WORKERS) n_threads = MAX_WORKERS;
     r->n_threads = n_threads;
     if (!batch_bytes && getenv("PSSBAM_BATCH_BYTES")) batch_bytes = (size_t)strtoull(getenv("PSSBAM_BATCH_BYTES"), NULL, 10);
     r->ucap = batch_bytes ? batch_bytes : (size_t)256 << 20;
     if (r->ucap < 4 * BGZF_MAX_BLOCK) r->ucap = 4 * BGZF_MAX_BLOCK;
-    r->ccap = r->ucap / 2 + 2 * BGZF_MAX_BLOCK; /* slab of compressed input per refill */
-    r->cbuf = (uint8_t *)malloc(r->ccap);
+    if (r->ucap > (size_t)2 << 30) r->ucap = (size_t)2 << 30; /* record offsets are 32-bit */
     /* page-aligned so the caller can register it for DMA; slack for device over-reads */
     r->ucap = (r->ucap + 4095) & ~(size_t)4095;
-    if (posix_memalign((void **)&r->ubase, 4096, 2 * (r->ucap + UPAD)) != 0) r->ubase = NULL;
-    r->ubuf = r->ubase;
-    r->cur = 0;
-    pthread_mutex_init(&r->mu, NULL);
-    if (!r->cbuf || !r->ubase) {
-        if (err) snprintf(err, errlen, "out of memory");
-        bam_reader_close(r);
-        return NULL;
+    if (posix_memalign((void **)&r->ubase, 4096, 2 * (r->ucap + UPAD)) != 0) {
+        r->ubase = NULL;
+        set_err(r, "out of memory");
+        goto fail;
     }
-    if (parse_header(r)) {
-        if (err) snprintf(err, errlen, "%s: %s", path, r->err);
-        bam_reader_close(r);
-        return NULL;
+    r->slot[0].buf = r->ubase;
+    r->slot[1].buf = r->ubase + r->ucap + UPAD;
+
+    /* the producer counts as one inflater */
+    for (int t = 0; t < n_threads - 1; t++) {
+        if (pthread_create(&r->worker[r->n_workers], NULL, worker_main, r) != 0) break;
+        r->n_workers++;
     }
+    if (pthread_create(&r->producer, NULL, producer_main, r) != 0) { set_err(r, "cannot start the reader thread"); goto fail; }
+    r->producer_started = 1;
+    pthread_mutex_lock(&r->mu);
+    while (r->header_state == 0) pthread_cond_wait(&r->cv, &r->mu);
+    const int hs = r->header_state;
+    pthread_mutex_unlock(&r->mu);
+    if (hs < 0) goto fail;
     return r;
+fail:
+    if (err) snprintf(err, errlen, "%s%s%s", r->fd >= 0 ? path : "", r->fd >= 0 ? ": " : "", r->err);
+    bam_reader_close(r);
+    return NULL;
 }
 
 const bam_header *bam_reader_header(const bam_reader *r) { return &r->hdr; }
@@ -381,68 +462,59 @@ void bam_reader_buffer(const bam_reader *r, void **base, size_t *bytes)
 
 int64_t bam_reader_next(bam_reader *r, const uint8_t **records, const uint32_t **offsets, size_t *nbytes)
 {
-    /* the batch handed out by the previous call is finished with: switch to the one the
-     * background thread has been inflating meanwhile */
-    if (r->bg_running || r->bg_pending) {
-        r->bg_pending = 0;
-        if (bg_take(r)) return -1;
+    pthread_mutex_lock(&r->mu);
+    if (r->held >= 0) { /* the batch handed out by the previous call is finished with */
+        r->slot[r->held].state = SLOT_FREE;
+        r->held = -1;
+        pthread_cond_broadcast(&r->cv);
     }
-    for (;;) {
-        /* index whole records in [upos, ulen) */
-        size_t o = r->upos, n = 0;
-        const size_t limit = r->upos + (((size_t)1 << 32) - (1u << 20));
-        while (o + 4 <= r->ulen && o < limit) {
-            uint32_t bs = le32(r->ubuf + o);
-            if (bs < 32) { set_err(r, "alignment record with block_size %u < 32", bs); return -1; }
-            if (o + 4 + (size_t)bs > r->ulen) break;
-            if (n + 2 > r->offs_cap) {
-                r->offs_cap = r->offs_cap ? r->offs_cap * 2 : (1u << 20);
-                r->offs = (uint32_t *)realloc(r->offs, r->offs_cap * sizeof(uint32_t));
-            }
-            r->offs[n++] = (uint32_t)(o - r->upos);
-            o += 4 + (size_t)bs;
-        }
-        if (n > 0) {
-            r->offs[n] = (uint32_t)(o - r->upos);
-            *records = r->ubuf + r->upos;
-            *offsets = r->offs;
-            *nbytes = o - r->upos;
-            r->upos = o;
-            /* start inflating the following batch behind the caller's work on this one; the
-             * unconsumed tail (a partial record) is carried over by the fill itself */
-            bg_start(r, r->ubuf + o, r->ulen - o);
-            r->bg_pending = 1;
-            return (int64_t)n;
-        }
-        /* nothing whole in hand: inflate more, synchronously */
-        size_t have = r->ulen - r->upos;
-        if (have >= 4) {
-            uint32_t bs = le32(r->ubuf + r->upos);
-            if (4 + (size_t)bs > r->ucap) { set_err(r, "alignment record of %u bytes exceeds the batch buffer", bs); return -1; }
-        }
-        if (batch_fill(r)) return -1;
-        if (r->ulen - r->upos == have) {
-            if (have) { set_err(r, "truncated alignment record at end of file"); return -1; }
-            return 0;
-        }
-    }
+    slot_t *s = &r->slot[r->take];
+    while (s->state != SLOT_READY) pthread_cond_wait(&r->cv, &r->mu);
+    pthread_mutex_unlock(&r->mu);
+    if (s->rc) return -1;
+    if (s->eof) return 0;
+    r->held = r->take;
+    r->take ^= 1;
+    *records = s->buf + s->start;
+    *offsets = s->offs;
+    *nbytes = s->rec_end - s->start;
+    return (int64_t)s->n_recs;
 }
 
 void bam_reader_close(bam_reader *r)
 {
     if (!r) return;
-    if (r->bg_running) pthread_join(r->bg_thread, NULL);
+    if (r->producer_started) {
+        pthread_mutex_lock(&r->mu);
+        r->stop = 1;
+        pthread_cond_broadcast(&r->cv);
+        pthread_mutex_unlock(&r->mu);
+        pthread_join(r->producer, NULL);
+    }
+    if (r->n_workers) {
+        pthread_mutex_lock(&r->job_mu);
+        r->job_quit = 1;
+        pthread_cond_broadcast(&r->job_cv);
+        pthread_mutex_unlock(&r->job_mu);
+        for (int t = 0; t < r->n_workers; t++) pthread_join(r->worker[t], NULL);
+    }
+    if (r->mapped) munmap((void *)r->cdata, r->clen);
+    else free((void *)r->cdata);
     if (r->fd >= 0) close(r->fd);
-    free(r->cbuf);
     free(r->ubase);
     free(r->blk);
-    free(r->offs);
+    free(r->slot[0].offs);
+    free(r->slot[1].offs);
     free(r->hdr.text);
     if (r->hdr.ref_name)
         for (int32_t i = 0; i < r->hdr.n_ref; i++) free(r->hdr.ref_name[i]);
     free(r->hdr.ref_name);
     free(r->hdr.ref_len);
     pthread_mutex_destroy(&r->mu);
+    pthread_cond_destroy(&r->cv);
+    pthread_mutex_destroy(&r->job_mu);
+    pthread_cond_destroy(&r->job_cv);
+    pthread_cond_destroy(&r->done_cv);
     free(r);
 }
 

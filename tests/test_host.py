@@ -250,6 +250,57 @@ def test_bam_reader_roundtrip_through_bam2sam(host, tmp_path):
     assert pr.returncode != 0 and "bam2sam:" in pr.stderr
 
 
+def test_bam_reader_edge_inputs(host, tmp_path):
+    """header-only BAM, truncated files, a record larger than the batch buffer, input through a pipe"""
+    _, pkg = host
+    exe = pkg.PKG_DIR / "bin" / "bam2sam"
+    _, refs, recs = tl.fuzz_dataset(77, 400)
+    want = "".join(tl.sam_line(r) for r in recs).replace("\tchrNotInHeader\t", "\t*\t")
+
+    empty = tmp_path / "hdr_only.bam"
+    tl.write_bam(empty, refs, [])
+    pr = subprocess.run([str(exe), str(empty)], capture_output=True, text=True)
+    assert pr.returncode == 0 and pr.stdout == ""
+
+    zero = tmp_path / "zero.bam"
+    zero.write_bytes(b"")
+    pr = subprocess.run([str(exe), str(zero)], capture_output=True, text=True)
+    assert pr.returncode != 0 and "too short" in pr.stderr
+
+    good = tmp_path / "good.bam"
+    tl.write_bam(good, refs, recs, level=1, rng=np.random.default_rng(5), block=3000)
+    data = good.read_bytes()
+    # cut inside a BGZF block / cut on a block boundary but inside a record
+    cut = tmp_path / "cut.bam"
+    cut.write_bytes(data[: len(data) // 2])
+    pr = subprocess.run([str(exe), str(cut)], capture_output=True, text=True)
+    assert pr.returncode != 0 and "truncated" in pr.stderr
+    raw = tl.bam_bytes(refs, recs)
+    part = tmp_path / "part.bam"
+    part.write_bytes(tl.bgzf_block(raw[: len(raw) - 7], 1) if len(raw) - 7 < 0xFF00 else
+                     b"".join(tl.bgzf_block(raw[i:min(i + 0xFF00, len(raw) - 7)], 1) for i in range(0, len(raw) - 7, 0xFF00)))
+    pr = subprocess.run([str(exe), str(part)], capture_output=True, text=True)
+    assert pr.returncode != 0 and "truncated alignment record" in pr.stderr
+
+    # not a regular file: the reader falls back to reading the stream into memory
+    fifo = tmp_path / "in.fifo"
+    os.mkfifo(fifo)
+    feeder = subprocess.Popen(["sh", "-c", f"cat '{good}' > '{fifo}'"])
+    pr = subprocess.run([str(exe), str(fifo)], capture_output=True, text=True, timeout=60)
+    feeder.wait(timeout=60)
+    assert pr.returncode == 0 and pr.stdout == want
+
+    # one record longer than the (minimum, 256 KiB) batch buffer
+    big = tl.Rec(qname="big", flag=0, rname=refs[0][0], pos=1, mapq=30, cigar=[(300000, "M")], seq="A" * 300000)
+    bigf = tmp_path / "big.bam"
+    tl.write_bam(bigf, refs, [recs[0], big, recs[1]])
+    pr = subprocess.run([str(exe), str(bigf)], capture_output=True, text=True,
+                        env={**os.environ, "PSSBAM_BATCH_BYTES": "262144"})
+    assert pr.returncode != 0 and "exceeds the batch buffer" in pr.stderr
+    pr = subprocess.run([str(exe), str(bigf)], capture_output=True, text=True)
+    assert pr.returncode == 0 and pr.stdout.count("\n") == 3
+
+
 def test_front_end_argument_handling(host, tmp_path):
     _, pkg = host
     pss, fk = pkg.PKG_DIR / "bin" / "pss-bam", pkg.PKG_DIR / "bin" / "fragkon"
