@@ -267,7 +267,7 @@ __device__ __forceinline__ void tally_tiled_body(const TallyParams &P, const Tal
     const uint32_t T = P.reads_per_tile;   // <= TILED_MAX_T
     const uint32_t pieces = P.prefix_pieces;  // 16-byte pieces staged per record
     const uint64_t recs_limit = (P.recs_bytes + 15ull) & ~15ull;  // the block is readable up to here
-    const uint32_t ablate = P.ablate;      // diagnostics only (PSSBAM_ABLATE): 1 no COLUMNS, 2 no position loop, 4 no CODES
+    const uint32_t ablate = P.ablate;      // diagnostics only (PSSBAM_ABLATE): 1 no COLUMNS, 2 no position loop, 4 no CODES, 128 no window gathers
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u, wave = tid >> 6;
@@ -350,10 +350,12 @@ __device__ __forceinline__ void tally_tiled_body(const TallyParams &P, const Tal
         if (cand) {
             const uint64_t ga = pl.gbase + (uint64_t)pl.s + (e ? (uint64_t)pl.L - 30ull : (uint64_t)-2ll);
             const uint32_t *pg = (const uint32_t *)(P.genome + (ga & ~3ull));
-            const Quad q0 = *(const Quad *)pg, q1 = *(const Quad *)(pg + 4);
+            if (!(ablate & 128u)) {
+                const Quad q0 = *(const Quad *)pg, q1 = *(const Quad *)(pg + 4);
 #pragma unroll
-            for (int k = 0; k < 4; k++) { gw[k] = q0.v[k]; gw[4 + k] = q1.v[k]; }
-            gw[8] = pg[8];
+                for (int k = 0; k < 4; k++) { gw[k] = q0.v[k]; gw[4 + k] = q1.v[k]; }
+                gw[8] = pg[8];
+            }
             gsh = (uint32_t)(ga & 3ull);
         }
         // read bases of this end as a nibble stream aligned with the window bytes: stream nibble

@@ -1,18 +1,23 @@
 /*
  * pss-bam_amd/host/bam_reader.c -- multi-threaded BGZF inflate + BAM framing.
  *
- * The compressed file is mmap()ed; one producer thread turns it into batches of whole raw
- * alignment records, ahead of the caller, through two batch slots:
- *   1. walk the 18-byte BGZF headers (BSIZE) from the current file offset and pick up each
- *      block's ISIZE from its trailer, until the slot is full; a running sum of the ISIZEs
- *      tells every block where its payload goes in the slot;
- *   2. a persistent pool of worker threads pulls block indices from a shared counter and
- *      inflates (raw deflate, zlib) straight from the mapping into place, checking CRC32 and
- *      ISIZE -- the page faults of the mapping are taken by the workers, in parallel;
- *   3. follow the block_size chain over the inflated bytes to index whole records; the
- *      trailing partial record is carried to the front of the next slot.
- * bam_reader_next() only hands a finished slot over and gives the previous one back, so the
- * caller's work on batch i (H2D copy + kernel) overlaps the inflate of batch i+1.
+ * The compressed file is mmap()ed and turned into batches of whole raw alignment records,
+ * ahead of the caller, by a three-stage pipeline over three batch slots:
+ *   1. FILL (producer thread): walk the 18-byte BGZF headers (BSIZE) from the current file
+ *      offset and pick up each block's ISIZE from its trailer, until the slot is full; a
+ *      running sum of the ISIZEs tells every block where its payload goes.  A persistent pool
+ *      of worker threads pulls block indices from a shared counter and inflates (raw deflate,
+ *      zlib) straight from the mapping into place, checking CRC32 and ISIZE -- the page faults
+ *      of the mapping are taken by the workers, in parallel.  The payload starts `gap` bytes
+ *      into the slot: room for the partial record the previous batch ended with, which is
+ *      not known yet.
+ *   2. INDEX (indexer thread): put the carried partial record in front of the payload, follow
+ *      the block_size chain to index whole records (a dependent-load chain, one cache miss per
+ *      record: as expensive as the inflate of the batch on 32 threads, hence its own stage),
+ *      keep the trailing partial record for the next batch.
+ *   3. bam_reader_next() hands an indexed slot over and gives the previous one back.
+ * So the caller's work on batch i (H2D copy + kernel), the indexing of batch i+1 and the
+ * inflate of batch i+2 overlap.
  * Inputs that cannot be mapped (pipes) are read into memory first.
  * Format references: SAM/BAM specification sections 4.1 (BGZF) and 4.2 (BAM).
  */
@@ -45,11 +50,15 @@ typedef struct {
     size_t uoff;     /* destination offset in the batch slot        */
 } blk_t;
 
-enum { SLOT_FREE = 0, SLOT_READY = 1 };
+#define N_SLOTS 3
+enum { SLOT_FREE = 0, SLOT_FILLED = 1, SLOT_READY = 2 };
 
 typedef struct {
-    uint8_t *buf;      /* ucap + UPAD bytes                                               */
-    size_t start;      /* first record byte (behind the BAM header in the first batch)    */
+    uint8_t *buf;      /* gap + ucap + UPAD bytes                                         */
+    size_t len;        /* end of the inflated payload (it starts at `gap`)                */
+    int full;          /* the fill stopped because the next block did not fit             */
+    size_t start;      /* first record byte (carry in front of the payload; behind the
+                          BAM header in the first batch)                                 */
     size_t rec_end;    /* end of the last whole record                                    */
     uint32_t *offs;    /* n_recs + 1 offsets relative to `start`                          */
     size_t offs_cap, n_recs;
@@ -67,21 +76,25 @@ struct bam_reader {
     /* batch slots, one allocation so a caller can page-lock it in one go */
     uint8_t *ubase;
     size_t ucap;
-    slot_t slot[2];
+    size_t gap;        /* bytes reserved in front of each slot's payload for the carry */
+    slot_t slot[N_SLOTS];
     int take;          /* slot the next bam_reader_next() returns   */
     int held;          /* slot the caller is working on, or -1      */
     /* producer */
-    pthread_t producer;
-    int producer_started;
+    pthread_t producer, indexer;
+    int producer_started, indexer_started;
+    uint8_t *carry;    /* indexer's copy of the partial record a batch ended with */
+    size_t carry_len, carry_cap;
     int stop;          /* guarded by mu */
     int header_state;  /* 0 pending, 1 parsed, -1 failed; guarded by mu */
+    int hdr_parsed;    /* parse_header() got through */
     pthread_mutex_t mu;
     pthread_cond_t cv;
     blk_t *blk;
     size_t n_blk, blk_cap;
     bam_header hdr;
     char err[256];
-    double inflate_s;
+    double inflate_s, scan_s, index_s, wait_s; /* producer's wall time per phase */
     /* inflate workers */
     int n_threads;     /* pool size; <= 1 means inflate in the producer itself */
     pthread_t worker[MAX_WORKERS];
@@ -216,14 +229,14 @@ static int run_inflate(bam_reader *r, uint8_t *dst)
 
 /* ---- producer ------------------------------------------------------------------------------- */
 
-/* Fills `dst` with [carry bytes | as many whole inflated BGZF blocks as fit]; *len_out = valid
- * bytes, *full = stopped because the next block does not fit (not because the input ended). */
-static int fill_buffer(bam_reader *r, uint8_t *dst, const uint8_t *carry, size_t carry_len, size_t *len_out, int *full)
+/* Inflates as many whole BGZF blocks as fit into dst[first .. first + ucap); *len_out = end of
+ * the payload, *full = stopped because the next block does not fit (not because the input ended). */
+static int fill_buffer(bam_reader *r, uint8_t *dst, size_t first, size_t *len_out, int *full)
 {
-    if (carry_len) memmove(dst, carry, carry_len);
+    const double t0 = now_s();
     r->n_blk = 0;
     *full = 0;
-    size_t uoff = carry_len;
+    size_t uoff = first;
     while (r->cpos < r->clen) {
         uint32_t xlen = 0;
         const size_t avail = r->clen - r->cpos;
@@ -233,7 +246,7 @@ static int fill_buffer(bam_reader *r, uint8_t *dst, const uint8_t *carry, size_t
         if ((size_t)bl < 12u + xlen + 8u) { set_err(r, "BGZF block shorter than its own header"); return -1; }
         const uint32_t isize = le32(r->cdata + r->cpos + bl - 4);
         if (isize > BGZF_MAX_BLOCK) { set_err(r, "BGZF ISIZE %u exceeds 64 KiB", isize); return -1; }
-        if (uoff + isize > r->ucap) { *full = 1; break; }
+        if (uoff + isize > first + r->ucap) { *full = 1; break; }
         if (r->n_blk == r->blk_cap) {
             const size_t cap = r->blk_cap ? r->blk_cap * 2 : 8192;
             blk_t *nb = (blk_t *)realloc(r->blk, cap * sizeof(blk_t));
@@ -246,6 +259,7 @@ static int fill_buffer(bam_reader *r, uint8_t *dst, const uint8_t *carry, size_t
         r->cpos += (size_t)bl;
     }
     *len_out = uoff;
+    r->scan_s += now_s() - t0;
     return r->n_blk ? run_inflate(r, dst) : 0;
 }
 
@@ -282,6 +296,7 @@ static int parse_header(bam_reader *r, const uint8_t *p, size_t len, int input_d
         o += 8 + l_name;
     }
     *end_out = o;
+    r->hdr_parsed = 1;
     return 0;
 }
 
@@ -309,42 +324,96 @@ static int index_slot(bam_reader *r, slot_t *s, size_t len)
     return 0;
 }
 
+static void slot_publish(bam_reader *r, slot_t *s, int state)
+{
+    pthread_mutex_lock(&r->mu);
+    s->state = state;
+    pthread_cond_broadcast(&r->cv);
+    pthread_mutex_unlock(&r->mu);
+}
+
+/* waits until the slot is in `state`; 0 ok / 1 the reader is being closed */
+static int slot_await(bam_reader *r, slot_t *s, int state)
+{
+    pthread_mutex_lock(&r->mu);
+    while (s->state != state && !r->stop) pthread_cond_wait(&r->cv, &r->mu);
+    const int stop = r->stop;
+    pthread_mutex_unlock(&r->mu);
+    return stop;
+}
+
+/* stage 1: inflate the next run of BGZF blocks into each free slot */
 static void *producer_main(void *arg)
 {
     bam_reader *r = (bam_reader *)arg;
-    const uint8_t *carry = NULL;
-    size_t carry_len = 0;
-    int first = 1;
-    for (int w = 0;; w ^= 1) {
+    for (int w = 0;; w = (w + 1) % N_SLOTS) {
         slot_t *s = &r->slot[w];
-        pthread_mutex_lock(&r->mu);
-        while (s->state != SLOT_FREE && !r->stop) pthread_cond_wait(&r->cv, &r->mu);
-        const int stop = r->stop;
-        pthread_mutex_unlock(&r->mu);
-        if (stop) break;
+        const double tw = now_s();
+        if (slot_await(r, s, SLOT_FREE)) break;
+        r->wait_s += now_s() - tw;
+        s->len = r->gap;
+        s->rc = fill_buffer(r, s->buf, r->gap, &s->len, &s->full);
+        const int last = s->rc != 0 || s->len == r->gap; /* error, or nothing left to inflate */
+        slot_publish(r, s, SLOT_FILLED);
+        if (last) break;
+    }
+    return NULL;
+}
 
-        size_t len = 0;
-        int full = 0;
-        int rc = fill_buffer(r, s->buf, carry, carry_len, &len, &full);
-        s->start = 0;
-        if (rc == 0 && first) rc = parse_header(r, s->buf, len, !full, &s->start);
-        if (rc == 0) rc = index_slot(r, s, len);
-        if (rc == 0 && s->n_recs == 0 && len > s->start) {
+/* stage 2: carry + header + record index of each filled slot */
+static void *indexer_main(void *arg)
+{
+    bam_reader *r = (bam_reader *)arg;
+    int first = 1;
+    for (int w = 0;; w = (w + 1) % N_SLOTS) {
+        slot_t *s = &r->slot[w];
+        if (slot_await(r, s, SLOT_FILLED)) break;
+        const double t0 = now_s();
+        int rc = s->rc;
+        s->start = s->rec_end = r->gap;
+        s->n_recs = 0;
+        if (rc == 0 && r->carry_len > r->gap) {
+            set_err(r, "alignment record of more than %zu bytes exceeds the batch buffer", r->gap);
+            rc = -1;
+        }
+        if (rc == 0) {
+            s->start = r->gap - r->carry_len;
+            if (r->carry_len) memcpy(s->buf + s->start, r->carry, r->carry_len);
+            if (first) {
+                size_t hdr_end = 0;
+                rc = parse_header(r, s->buf + s->start, s->len - s->start, !s->full, &hdr_end);
+                s->start += hdr_end;
+            }
+        }
+        if (rc == 0) rc = index_slot(r, s, s->len);
+        if (rc == 0 && s->n_recs == 0 && s->len > s->start) {
             /* bytes in hand but not one whole record */
-            if (full) {
-                set_err(r, "alignment record of %u bytes exceeds the batch buffer", len - s->start >= 4 ? le32(s->buf + s->start) : 0u);
+            if (s->full) {
+                set_err(r, "alignment record of %u bytes exceeds the batch buffer",
+                        s->len - s->start >= 4 ? le32(s->buf + s->start) : 0u);
             } else {
                 set_err(r, "truncated alignment record at end of file");
             }
             rc = -1;
         }
+        if (rc == 0) { /* keep the partial record behind the last whole one */
+            const size_t n = s->len - s->rec_end;
+            if (n > r->carry_cap) {
+                uint8_t *nc = (uint8_t *)realloc(r->carry, n + 4096);
+                if (!nc) { set_err(r, "out of memory"); rc = -1; }
+                else { r->carry = nc; r->carry_cap = n + 4096; }
+            }
+            if (rc == 0) {
+                if (n) memcpy(r->carry, s->buf + s->rec_end, n);
+                r->carry_len = n;
+            }
+        }
         s->rc = rc;
         s->eof = rc == 0 && s->n_recs == 0;
-        carry = s->buf + s->rec_end;
-        carry_len = rc == 0 ? len - s->rec_end : 0;
+        r->index_s += now_s() - t0;
 
         pthread_mutex_lock(&r->mu);
-        if (first) r->header_state = (rc == 0 || s->start) ? 1 : -1;
+        if (first) r->header_state = (rc == 0 || r->hdr_parsed) ? 1 : -1;
         s->state = SLOT_READY;
         pthread_cond_broadcast(&r->cv);
         pthread_mutex_unlock(&r->mu);
@@ -423,13 +492,15 @@ bam_reader *bam_reader_open(const char *path, int n_threads, size_t batch_bytes,
     if (r->ucap > (size_t)2 << 30) r->ucap = (size_t)2 << 30; /* record offsets are 32-bit */
     /* page-aligned so the caller can register it for DMA; slack for device over-reads */
     r->ucap = (r->ucap + 4095) & ~(size_t)4095;
-    if (posix_memalign((void **)&r->ubase, 4096, 2 * (r->ucap + UPAD)) != 0) {
+    r->gap = r->ucap / 4 < ((size_t)16 << 20) ? r->ucap / 4 : (size_t)16 << 20;
+    r->gap = (r->gap + 4095) & ~(size_t)4095;
+    const size_t slot_bytes = r->gap + r->ucap + UPAD;
+    if (posix_memalign((void **)&r->ubase, 4096, N_SLOTS * slot_bytes) != 0) {
         r->ubase = NULL;
         set_err(r, "out of memory");
         goto fail;
     }
-    r->slot[0].buf = r->ubase;
-    r->slot[1].buf = r->ubase + r->ucap + UPAD;
+    for (int w = 0; w < N_SLOTS; w++) r->slot[w].buf = r->ubase + (size_t)w * slot_bytes;
 
     /* the producer counts as one inflater */
     for (int t = 0; t < n_threads - 1; t++) {
@@ -438,6 +509,8 @@ bam_reader *bam_reader_open(const char *path, int n_threads, size_t batch_bytes,
     }
     if (pthread_create(&r->producer, NULL, producer_main, r) != 0) { set_err(r, "cannot start the reader thread"); goto fail; }
     r->producer_started = 1;
+    if (pthread_create(&r->indexer, NULL, indexer_main, r) != 0) { set_err(r, "cannot start the indexer thread"); goto fail; }
+    r->indexer_started = 1;
     pthread_mutex_lock(&r->mu);
     while (r->header_state == 0) pthread_cond_wait(&r->cv, &r->mu);
     const int hs = r->header_state;
@@ -454,10 +527,18 @@ const bam_header *bam_reader_header(const bam_reader *r) { return &r->hdr; }
 const char *bam_reader_error(const bam_reader *r) { return r->err; }
 double bam_reader_inflate_seconds(const bam_reader *r) { return r->inflate_s; }
 
+void bam_reader_phase_seconds(const bam_reader *r, double out[4])
+{
+    out[0] = r->scan_s;
+    out[1] = r->inflate_s;
+    out[2] = r->index_s;
+    out[3] = r->wait_s;
+}
+
 void bam_reader_buffer(const bam_reader *r, void **base, size_t *bytes)
 {
     *base = r->ubase;
-    *bytes = 2 * (r->ucap + UPAD);
+    *bytes = N_SLOTS * (r->gap + r->ucap + UPAD);
 }
 
 int64_t bam_reader_next(bam_reader *r, const uint8_t **records, const uint32_t **offsets, size_t *nbytes)
@@ -474,7 +555,7 @@ int64_t bam_reader_next(bam_reader *r, const uint8_t **records, const uint32_t *
     if (s->rc) return -1;
     if (s->eof) return 0;
     r->held = r->take;
-    r->take ^= 1;
+    r->take = (r->take + 1) % N_SLOTS;
     *records = s->buf + s->start;
     *offsets = s->offs;
     *nbytes = s->rec_end - s->start;
@@ -484,13 +565,12 @@ int64_t bam_reader_next(bam_reader *r, const uint8_t **records, const uint32_t *
 void bam_reader_close(bam_reader *r)
 {
     if (!r) return;
-    if (r->producer_started) {
-        pthread_mutex_lock(&r->mu);
-        r->stop = 1;
-        pthread_cond_broadcast(&r->cv);
-        pthread_mutex_unlock(&r->mu);
-        pthread_join(r->producer, NULL);
-    }
+    pthread_mutex_lock(&r->mu);
+    r->stop = 1;
+    pthread_cond_broadcast(&r->cv);
+    pthread_mutex_unlock(&r->mu);
+    if (r->producer_started) pthread_join(r->producer, NULL);
+    if (r->indexer_started) pthread_join(r->indexer, NULL);
     if (r->n_workers) {
         pthread_mutex_lock(&r->job_mu);
         r->job_quit = 1;
@@ -503,8 +583,8 @@ void bam_reader_close(bam_reader *r)
     if (r->fd >= 0) close(r->fd);
     free(r->ubase);
     free(r->blk);
-    free(r->slot[0].offs);
-    free(r->slot[1].offs);
+    for (int w = 0; w < N_SLOTS; w++) free(r->slot[w].offs);
+    free(r->carry);
     free(r->hdr.text);
     if (r->hdr.ref_name)
         for (int32_t i = 0; i < r->hdr.n_ref; i++) free(r->hdr.ref_name[i]);

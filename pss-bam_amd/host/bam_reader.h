@@ -38,6 +38,9 @@ int64_t bam_reader_next(bam_reader *r, const uint8_t **records, const uint32_t *
 void bam_reader_buffer(const bam_reader *r, void **base, size_t *bytes);
 const char *bam_reader_error(const bam_reader *r);
 double bam_reader_inflate_seconds(const bam_reader *r); /* wall time spent inflating so far */
+/* the reader thread's wall time so far: [0] block-table walk + carry copy, [1] inflate,
+ * [2] record indexing, [3] waiting for the caller to give a batch slot back */
+void bam_reader_phase_seconds(const bam_reader *r, double out[4]);
 void bam_reader_close(bam_reader *r);
 
 /* SAM text of one record (no trailing newline handling surprises: ends with '\n'); returns

@@ -144,6 +144,11 @@ int run_tally(const pssbam_config *cfg, Genome *genome, const char *aln_path, in
     if (verbose)
         fprintf(stderr, "[pssbam] phases: open %.3f engine+genome %.3f pin %.3f read(wait) %.3f submit %.3f reduce+finish %.3f s\n",
                 t_open, t_engine, t_register, t_read, t_submit, t_finish);
+    if (verbose && rd) {
+        double ph[4];
+        bam_reader_phase_seconds(rd, ph);
+        fprintf(stderr, "[pssbam] reader thread: scan+carry %.3f inflate %.3f index %.3f wait-for-slot %.3f s\n", ph[0], ph[1], ph[2], ph[3]);
+    }
     res->inflate_s = rd ? bam_reader_inflate_seconds(rd) : 0.0;
     if (sd) res->stats[PSSBAM_ST_PARSE_SKIP] += sam_reader_lines_skipped(sd), res->stats[PSSBAM_ST_RECORDS] += sam_reader_lines_skipped(sd);
     res->n_gpus = n_gpus;
