@@ -8,6 +8,11 @@
  * (fasta-genome-io.c:105-148 / :157-198).  Contig storage grows geometrically per
  * contig; the reference's fixed 512 MiB staging buffer (:28) is only allocated when a
  * caller uses the record-at-a-time API (init_fasta_src / get_next_fa).
+ * Plain-text files are loaded by several threads (load_parallel below): the mapped file is
+ * cut at line starts -- every line start is in "body" state, whatever came before -- each
+ * piece is scanned for headers and base counts, the contigs are sized, and the pieces are
+ * compacted straight into place.  Same bytes out as the one-thread parser, which remains
+ * the path for .gz input, unmappable files and the over-long-contig corner.
  *
  * Behaviour kept, byte for byte, for well-formed input:
  *   - id = bytes after '>' up to the first isspace() byte            (:111-115)
@@ -25,6 +30,9 @@
 
 #include <errno.h>
 #include <fcntl.h>
+#include <pthread.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 /* byte classes for the block parser */
@@ -209,6 +217,241 @@ static int feed(Genome *g, parse_state *ps, const unsigned char *p, size_t n)
     return 0;
 }
 
+/* ------------------------------------------------------------------------------------ */
+/* multi-threaded loader for plain-text files                                            */
+/* ------------------------------------------------------------------------------------ */
+
+typedef struct {
+    size_t hdr;              /* offset of the '>' that opens this segment; (size_t)-1 = the
+                                piece's leading bytes, which continue the previous contig   */
+    size_t body_a, body_b;   /* body bytes of the segment within the file                   */
+    size_t n_bases;          /* non-white-space bytes in it                                 */
+    char *dst;               /* where they go (set when the contigs are sized)              */
+    char id[MAX_ID_LEN + 1];
+} fa_seg;
+
+typedef struct {
+    const unsigned char *data;
+    size_t a, b;             /* this piece: [a, b), a is a line start                      */
+    fa_seg *seg;
+    size_t n_seg, cap_seg;
+    int bad, open_header;    /* format violation; header line cut by the end of the file    */
+} fa_piece;
+
+typedef struct {
+    fa_piece *pc;
+    size_t n_pc;
+    size_t next;             /* shared cursor, guarded by mu */
+    pthread_mutex_t mu;
+    int pass;                /* 0 scan, 1 copy */
+} fa_job;
+
+static fa_seg *piece_add_seg(fa_piece *pc)
+{
+    if (pc->n_seg == pc->cap_seg) {
+        size_t cap = pc->cap_seg ? pc->cap_seg * 2 : 8;
+        fa_seg *ns = (fa_seg *)realloc(pc->seg, cap * sizeof(fa_seg));
+        if (!ns) return NULL;
+        pc->seg = ns;
+        pc->cap_seg = cap;
+    }
+    fa_seg *sg = &pc->seg[pc->n_seg++];
+    memset(sg, 0, sizeof *sg);
+    return sg;
+}
+
+/* pass 0: headers and base counts of one piece */
+static void piece_scan(fa_piece *pc)
+{
+    const unsigned char *p = pc->data;
+    size_t i = pc->a;
+    fa_seg *sg = piece_add_seg(pc);
+    if (!sg) { pc->bad = 1; return; }
+    sg->hdr = (size_t)-1;
+    sg->body_a = i;
+    while (i < pc->b) {
+        /* body: count bases up to the next '>' */
+        size_t n = 0;
+        while (i < pc->b) {
+            const unsigned char k = g_class[p[i]];
+            if (k == C_GT) break;
+            n += k == C_BASE;
+            i++;
+        }
+        sg->n_bases = n;
+        sg->body_b = i;
+        if (i == pc->b) break;
+        /* header line: id up to the first white-space byte, then the rest of the line */
+        sg = piece_add_seg(pc);
+        if (!sg) { pc->bad = 1; return; }
+        sg->hdr = i++;
+        size_t id_len = 0;
+        while (i < pc->b && !isspace(p[i])) {
+            if (id_len < MAX_ID_LEN) sg->id[id_len++] = (char)p[i];
+            else pc->bad = 1; /* precondition: ids <= MAX_ID_LEN */
+            i++;
+        }
+        sg->id[id_len] = '\0';
+        const unsigned char *nl = i < pc->b ? (const unsigned char *)memchr(p + i, '\n', pc->b - i) : NULL;
+        if (!nl) { pc->open_header = 1; sg->body_a = sg->body_b = pc->b; return; }
+        i = (size_t)(nl - p) + 1;
+        sg->body_a = sg->body_b = i;
+    }
+}
+
+/* pass 1: compact + upper-case every segment of one piece into place */
+static void piece_copy(const fa_piece *pc)
+{
+    for (size_t k = 0; k < pc->n_seg; k++) {
+        const fa_seg *sg = &pc->seg[k];
+        char *d = sg->dst;
+        if (!d) continue;
+        for (size_t i = sg->body_a; i < sg->body_b; i++) {
+            const unsigned char c = pc->data[i];
+            if (g_class[c] == C_BASE) *d++ = (char)g_upper[c];
+        }
+    }
+}
+
+static void *fa_worker(void *arg)
+{
+    fa_job *job = (fa_job *)arg;
+    for (;;) {
+        pthread_mutex_lock(&job->mu);
+        const size_t k = job->next++;
+        pthread_mutex_unlock(&job->mu);
+        if (k >= job->n_pc) break;
+        if (job->pass == 0) piece_scan(&job->pc[k]);
+        else piece_copy(&job->pc[k]);
+    }
+    return NULL;
+}
+
+static void fa_run(fa_job *job, int pass, int n_threads)
+{
+    pthread_t th[64];
+    int started = 0;
+    job->pass = pass;
+    job->next = 0;
+    for (int t = 0; t < n_threads - 1 && t < 64; t++)
+        if (pthread_create(&th[started], NULL, fa_worker, job) == 0) started++;
+    fa_worker(job);
+    for (int t = 0; t < started; t++) pthread_join(th[t], NULL);
+}
+
+/* Returns 1 = loaded into *out (NULL there = malformed input, already reported),
+ * 0 = not applicable, use the one-thread parser. */
+static int load_parallel(const char fn[], Genome **out)
+{
+    int n_threads = 16;
+    const char *ev = getenv("PSSBAM_FASTA_THREADS");
+    long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
+    if (ev) n_threads = atoi(ev);
+    if (ncpu > 0 && n_threads > ncpu) n_threads = (int)ncpu;
+    if (n_threads < 2) return 0;
+
+    int fd = open(fn, O_RDONLY);
+    struct stat st;
+    if (fd < 0) return 0; /* the serial path reports it */
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < (off_t)(1 << 20)) { close(fd); return 0; }
+    const size_t size = (size_t)st.st_size;
+    const unsigned char *data = (const unsigned char *)mmap(NULL, size, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (data == (const unsigned char *)MAP_FAILED) return 0;
+    (void)madvise((void *)data, size, MADV_SEQUENTIAL);
+
+    int applicable = 1, bad = 0;
+    Genome *genome = NULL;
+    fa_job job;
+    memset(&job, 0, sizeof job);
+    pthread_mutex_init(&job.mu, NULL);
+    /* pieces of 64 KiB .. 8 MiB (a few per thread), each starting right behind a '\n' */
+    size_t want = size / (4u * (size_t)n_threads);
+    if (want > (8u << 20)) want = 8u << 20;
+    if (want < (64u << 10)) want = 64u << 10;
+    job.pc = (fa_piece *)calloc(size / want + 2, sizeof(fa_piece));
+    if (!job.pc) { applicable = 0; goto out; }
+    for (size_t a = 0; a < size;) {
+        size_t b = a + want;
+        if (b >= size) b = size;
+        else {
+            const unsigned char *nl = (const unsigned char *)memchr(data + b, '\n', size - b);
+            b = nl ? (size_t)(nl - data) + 1 : size;
+        }
+        job.pc[job.n_pc].data = data;
+        job.pc[job.n_pc].a = a;
+        job.pc[job.n_pc].b = b;
+        job.n_pc++;
+        a = b;
+    }
+    if (data[0] != '>') bad = 1; /* precondition: starts with '>' */
+    if (!bad) fa_run(&job, 0, n_threads);
+
+    /* size the contigs: segments in file order; a leading segment continues the open contig */
+    genome = (Genome *)malloc(sizeof(Genome));
+    genome->seqs = (Seq **)malloc(sizeof(Seq *) * MAX_GENOME_SEQS);
+    genome->dummy = (Seq *)calloc(1, sizeof(Seq));
+    genome->n_seqs = 0;
+    for (int round = 0; round < 2 && !bad && applicable; round++) {
+        /* round 0 adds up lengths, round 1 (after allocation) hands out destinations */
+        Seq *cur = NULL;
+        size_t idx = 0, fill = 0;
+        for (size_t k = 0; k < job.n_pc && !bad; k++) {
+            fa_piece *pc = &job.pc[k];
+            if (round == 0 && (pc->bad || (pc->open_header))) { bad = 1; break; }
+            for (size_t q = 0; q < pc->n_seg; q++) {
+                fa_seg *sg = &pc->seg[q];
+                if (sg->hdr != (size_t)-1) {
+                    if (round == 0) {
+                        if (genome->n_seqs >= MAX_GENOME_SEQS) { applicable = 0; break; } /* rare: let the serial parser decide */
+                        cur = (Seq *)calloc(1, sizeof(Seq));
+                        if (!cur) { applicable = 0; break; }
+                        strcpy(cur->id, sg->id);
+                        genome->seqs[genome->n_seqs++] = cur;
+                    } else {
+                        cur = genome->seqs[idx++];
+                        fill = 0;
+                    }
+                }
+                if (!cur) continue; /* the empty lead-in of the first piece (the file starts with '>') */
+                if (round == 0) cur->len += sg->n_bases;
+                else { sg->dst = cur->seq + fill; fill += sg->n_bases; }
+            }
+            if (!applicable) break;
+        }
+        if (round == 0 && !bad && applicable) {
+            for (size_t c = 0; c < genome->n_seqs; c++) {
+                Seq *sq = genome->seqs[c];
+                if (sq->len > (size_t)MAX_SEQ_LEN) { applicable = 0; break; } /* truncation corner: serial parser */
+                sq->seq = (char *)malloc(sq->len + 1);
+                if (!sq->seq) { applicable = 0; break; }
+                sq->seq[sq->len] = '\0';
+            }
+        }
+    }
+    if (!bad && applicable) fa_run(&job, 1, n_threads);
+
+out:
+    for (size_t k = 0; k < job.n_pc; k++) free(job.pc[k].seg);
+    free(job.pc);
+    pthread_mutex_destroy(&job.mu);
+    munmap((void *)data, size);
+    if (!applicable) {
+        if (genome) destroy_genome(genome);
+        return 0;
+    }
+    if (bad) {
+        fprintf(stderr, "%s: malformed FASTA (must start with '>', header lines end in newline, ids <= %d)\n",
+                fn, MAX_ID_LEN);
+        destroy_genome(genome);
+        *out = NULL;
+        return 1;
+    }
+    qsort(genome->seqs, genome->n_seqs, sizeof(Seq *), chr_cmp);
+    *out = genome;
+    return 1;
+}
+
 Genome *init_genome(const char fn[])
 {
     Genome *genome;
@@ -222,6 +465,7 @@ Genome *init_genome(const char fn[])
     if (fn == NULL) return NULL;
     memset(&src, 0, sizeof src);
     src.gz = is_gz(fn);
+    if (!src.gz && load_parallel(fn, &genome)) return genome;
     if (src.gz) {
         src.zf = gzopen(fn, "rb");
         if (!src.zf) {

@@ -93,6 +93,56 @@ def test_genome_loader_odd_layouts(host, tmp_path, oracle):
     assert not L.init_genome(str(tmp_path / "missing.fa").encode())
 
 
+def test_genome_loader_parallel_equals_serial(host, tmp_path, oracle):  # noqa: C901
+    """files above 1 MiB take the multi-threaded path: same contigs as the one-thread parser and
+    as the oracle's loader, for layouts that stress the piece stitching (a '>' glued to a body
+    line, very long and very short lines, CRLF, empty contigs, a contig spanning many pieces)"""
+    L, _ = host
+    rng = np.random.default_rng(12)
+    big = tl.random_contig(rng, 2_200_000)
+    contigs = [("chrBig", big), ("empty1", ""), ("chrLongLine", tl.random_contig(rng, 400_000)),
+               ("tiny", "acgtn"), ("chrCR", tl.random_contig(rng, 300_000)), ("last", tl.random_contig(rng, 1000))]
+    fa = tmp_path / "par.fa"
+    with open(fa, "wb") as fh:
+        fh.write(b">chrBig some description > with a bracket\n")
+        for i in range(0, len(big), 71):
+            fh.write(big[i:i + 71].encode() + b"\n")
+        fh.write(b">empty1\n")
+        fh.write(b">chrLongLine\n" + contigs[2][1].encode() + b"\n")          # one 400 kb line
+        fh.write(b">tiny\tdescr\nac\ngt\nn")                                  # next '>' glued to the body line
+        fh.write(b">chrCR x\r\n")
+        for i in range(0, 300_000, 50):
+            fh.write(contigs[4][1][i:i + 50].encode() + b"\r\n")
+        fh.write(b"\n\n>last\n" + contigs[5][1].encode())                      # no final newline
+    assert fa.stat().st_size > (1 << 20)
+    want = sorted((cid, seq.upper().encode()) for cid, seq in contigs)
+    for threads in ("1", "3", "16"):
+        os.environ["PSSBAM_FASTA_THREADS"] = threads
+        try:
+            g, got = _genome_contents(L, fa)
+        finally:
+            del os.environ["PSSBAM_FASTA_THREADS"]
+        assert [(a, b) for a, b, _ in got] == want, threads
+        L.destroy_genome(g)
+    # the oracle's loader (restating fasta-genome-io.c) sees the same genome: k-mer census of both
+    og = oracle.load_genome(fa)
+    os.environ["PSSBAM_FASTA_THREADS"] = "16"
+    try:
+        g, got = _genome_contents(L, fa)
+    finally:
+        del os.environ["PSSBAM_FASTA_THREADS"]
+    mine = oracle.genome_from_arrays([(a, np.frombuffer(b, dtype=np.uint8).copy()) for a, b, _ in got])
+    assert np.array_equal(oracle.genome_kmer_count(og, 5), oracle.genome_kmer_count(mine, 5))
+    L.destroy_genome(g)
+    # malformed: a header line cut by the end of the file, bytes before the first '>'
+    cut = tmp_path / "cut.fa"
+    cut.write_bytes(fa.read_bytes() + b"\n>unterminated header")
+    assert not L.init_genome(str(cut).encode())
+    pre = tmp_path / "pre.fa"
+    pre.write_bytes(b"ACGT\n" + fa.read_bytes())
+    assert not L.init_genome(str(pre).encode())
+
+
 def test_genome_loader_equals_oracle_on_golden(host, oracle):
     L, _ = host
     for ds in MANIFEST["datasets"].values():
