@@ -67,6 +67,8 @@ def main():
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 simple, 2 tiled")
     ap.add_argument("--cpu-sample", type=int, default=2_000_000, help="reads timed on the host reference")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-cores", type=int, default=1,
+                    help="> 1: also time one reference process per core on disjoint shards (SURVEY 8d's all-cores figure)")
     ap.add_argument("--scale-genome", type=float, default=1.0)
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the counter reduce even with one rank")
     args = ap.parse_args()
@@ -256,7 +258,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"], out["parity_check"] = cpu_baseline(pkg, synth, eng, cfg, cd, region_len, klen,
-                                                                    min(args.cpu_sample, per_gpu), names)
+                                                                    min(args.cpu_sample, per_gpu), names, args.cpu_cores)
         except Exception as ex:  # the baseline must never sink the GPU number
             out["cpu_baseline"] = {"value": None, "unit": "reads/s", "cores": 1, "kind": "reference",
                                    "sample": f"failed: {ex!r}"}
@@ -267,7 +269,7 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(pkg, synth, eng, cfg, cd, region_len, klen, n_sample, names):
+def cpu_baseline(pkg, synth, eng, cfg, cd, region_len, klen, n_sample, names, cpu_cores=1):
     """Times oracle/_ref/pss-bam.O2 (unmodified reference, compiled in the build container)
     on the first n_sample reads of the SORTED stream, fed as SAM text (no inflate cost charged
     to it), and checks the engine's tables for the same reads against the reference's."""
@@ -327,10 +329,61 @@ def cpu_baseline(pkg, synth, eng, cfg, cd, region_len, klen, n_sample, names):
     ok = bool(np.array_equal(got.fwd, want[0]) and np.array_equal(got.rev, want[1]))
     parity = (f"bit-exact vs {kind} on the {n_sample}-read CPU sample" if ok
               else f"MISMATCH vs {kind} on the CPU sample")
+    out = {"value": value, "unit": "reads/s", "cores": 1, "kind": kind, "sample": sample}
+    if cpu_cores > 1 and have_ref:
+        out["all_cores"] = cpu_all_cores(pkg, synth, scfg, region_len, names, tmp, o, cpu_cores,
+                                         max(200_000, n_sample // 4))
     for p in tmp.iterdir():
         p.unlink()
     tmp.rmdir()
-    return ({"value": value, "unit": "reads/s", "cores": 1, "kind": kind, "sample": sample}, parity)
+    return (out, parity)
+
+
+def cpu_all_cores(pkg, synth, scfg, region_len, names, tmp, o, cores, per_shard):
+    """one unmodified reference process per core on disjoint consecutive shards of the
+    sorted stream, tables summed (tallies are additive) and checked against the engine's tables
+    for the same reads.  Load time (every process parses the FASTA) is measured by the same
+    number of concurrent processes on an empty SAM and subtracted."""
+    import numpy as np
+    import pssbam_testlib as tl
+    from concurrent.futures import ThreadPoolExecutor
+
+    threads = os.cpu_count() or 8
+    total = cores * per_shard
+    recs, offs = synth.records_host(scfg, total - 1, 1, threads=1)   # the last read tells how many contigs are needed
+    last_contig = int(np.frombuffer(recs[4:8].tobytes(), dtype="<i4")[0])
+    fa, empty = tmp / "ref_all.fa", tmp / "empty_all.sam"
+    synth.fasta_host(scfg, fa, 0, last_contig + 1, threads=threads)
+    synth.sam_host(scfg, 0, 0, empty)
+    with ThreadPoolExecutor(min(threads, 32)) as ex:   # the writers release the GIL
+        list(ex.map(lambda k: synth.sam_host(scfg, k * per_shard, per_shard, tmp / f"shard{k}.sam"), range(cores)))
+
+    def wave(inputs, tag):
+        t = time.perf_counter()
+        with ThreadPoolExecutor(cores) as ex:
+            res = list(ex.map(lambda kv: tl.run_ref_pss(fa, kv[1], tmp / f"{tag}{kv[0]}", o, variant="pss-bam.O2",
+                                                        timeout=3000)[:2], enumerate(inputs)))
+        return time.perf_counter() - t, res
+
+    t_load, _ = wave([empty] * cores, "l")
+    t_full, res = wave([tmp / f"shard{k}.sam" for k in range(cores)], "s")
+    fwd = sum(r[0].astype(np.uint64) for r in res)
+    rev = sum(r[1].astype(np.uint64) for r in res)
+    e2 = pkg.Engine(pss=dict(region_len=region_len))
+    e2.set_genome_arrays([(names[k], synth.genome_host(scfg, k, threads=threads)) for k in range(last_contig + 1)])
+    e2.set_references(names)
+    step = 8_000_000   # record blocks stay below 4 GiB
+    for a in range(0, total, step):
+        recs, offs = synth.records_host(scfg, a, min(step, total - a), threads=threads)
+        e2.submit(recs, offs)
+    got = e2.finish()
+    e2.close()
+    ok = bool(np.array_equal(got.fwd, fwd) and np.array_equal(got.rev, rev))
+    return {"value": total / max(t_full - t_load, 1e-9), "unit": "reads/s", "cores": cores,
+            "sample": f"{cores} concurrent oracle/_ref/pss-bam.O2 processes x {per_shard} reads each (consecutive shards of "
+                      f"the sorted stream, FASTA of contigs 0..{last_contig}); wall {t_full:.1f}s minus {t_load:.1f}s for the "
+                      f"same {cores} processes on an empty SAM",
+            "parity_check": "summed tables bit-exact vs the engine" if ok else "MISMATCH vs the engine"}
 
 
 if __name__ == "__main__":

@@ -7,7 +7,7 @@
  *      offset and pick up each block's ISIZE from its trailer, until the slot is full; a
  *      running sum of the ISIZEs tells every block where its payload goes.  A persistent pool
  *      of worker threads pulls block indices from a shared counter and inflates (raw deflate,
- *      zlib) straight from the mapping into place, checking CRC32 and ISIZE -- the page faults
+ *      inflate_fast.c) straight from the mapping into place, checking CRC32 and ISIZE -- the page faults
  *      of the mapping are taken by the workers, in parallel.  The payload starts `gap` bytes
  *      into the slot: room for the partial record the previous batch ended with, which is
  *      not known yet.
@@ -22,6 +22,7 @@
  * Format references: SAM/BAM specification sections 4.1 (BGZF) and 4.2 (BAM).
  */
 #include "bam_reader.h"
+#include "inflate_fast.h"
 
 #include <errno.h>
 #include <fcntl.h>
@@ -35,12 +36,12 @@
 #include <sys/stat.h>
 #include <time.h>
 #include <unistd.h>
-#include <zlib.h>
 
 #define BGZF_MAX_BLOCK 65536u
 #define UPAD 4096u /* slack behind each batch buffer (device over-reads, page alignment) */
 #define MAX_WORKERS 64
 #define GRAB 8     /* blocks a worker takes per visit to the shared counter */
+#define PREFETCH_AHEAD 12u /* records the index walk prefetches ahead of itself */
 
 typedef struct {
     size_t coff;     /* offset of the block in the compressed input */
@@ -106,6 +107,7 @@ struct bam_reader {
     uint8_t *job_dst;
     atomic_size_t job_next;
     atomic_int job_failed;
+    pss_inflater *own_inf; /* the producer's own decoder state */
 };
 
 static void set_err(bam_reader *r, const char *fmt, ...)
@@ -148,7 +150,7 @@ static long bgzf_block_len(const uint8_t *p, size_t avail, uint32_t *xlen_out)
 /* ---- inflate workers ------------------------------------------------------------------------ */
 
 /* inflates blocks of the current job until the shared counter runs past the table */
-static void inflate_blocks(bam_reader *r, z_stream *zs)
+static void inflate_blocks(bam_reader *r, pss_inflater *inf)
 {
     for (;;) {
         const size_t i = atomic_fetch_add(&r->job_next, GRAB);
@@ -158,13 +160,8 @@ static void inflate_blocks(bam_reader *r, z_stream *zs)
             const uint8_t *src = r->cdata + b->coff;
             uint8_t *dst = r->job_dst + b->uoff;
             if (b->isize == 0) continue;
-            inflateReset(zs);
-            zs->next_in = (Bytef *)(src + 12 + b->xlen);
-            zs->avail_in = b->clen - 12 - b->xlen - 8;
-            zs->next_out = dst;
-            zs->avail_out = b->isize;
-            if (inflate(zs, Z_FINISH) != Z_STREAM_END || zs->avail_out != 0 ||
-                (uint32_t)crc32(crc32(0L, Z_NULL, 0), dst, b->isize) != le32(src + b->clen - 8))
+            if (pss_inflate_raw(inf, src + 12 + b->xlen, b->clen - 12 - b->xlen - 8, dst, b->isize) != 0 ||
+                pss_crc32(0, dst, b->isize) != le32(src + b->clen - 8))
                 atomic_store(&r->job_failed, 1);
         }
     }
@@ -174,9 +171,7 @@ static void *worker_main(void *arg)
 {
     bam_reader *r = (bam_reader *)arg;
     unsigned long seen = 0;
-    z_stream zs;
-    memset(&zs, 0, sizeof zs);
-    const int zok = inflateInit2(&zs, -15) == Z_OK;
+    pss_inflater *inf = (pss_inflater *)malloc(sizeof *inf);
     for (;;) {
         pthread_mutex_lock(&r->job_mu);
         while (r->job_gen == seen && !r->job_quit) pthread_cond_wait(&r->job_cv, &r->job_mu);
@@ -184,12 +179,12 @@ static void *worker_main(void *arg)
         const int quit = r->job_quit;
         pthread_mutex_unlock(&r->job_mu);
         if (quit) break;
-        if (zok) inflate_blocks(r, &zs);
+        if (inf) inflate_blocks(r, inf);
         pthread_mutex_lock(&r->job_mu);
         if (--r->job_active == 0) pthread_cond_signal(&r->done_cv);
         pthread_mutex_unlock(&r->job_mu);
     }
-    if (zok) inflateEnd(&zs);
+    free(inf);
     return NULL;
 }
 
@@ -207,16 +202,9 @@ static int run_inflate(bam_reader *r, uint8_t *dst)
         pthread_cond_broadcast(&r->job_cv);
         pthread_mutex_unlock(&r->job_mu);
     }
-    { /* the producer lends a hand (and is the only inflater when there is no pool) */
-        z_stream zs;
-        memset(&zs, 0, sizeof zs);
-        if (inflateInit2(&zs, -15) == Z_OK) {
-            inflate_blocks(r, &zs);
-            inflateEnd(&zs);
-        } else if (r->n_workers == 0) {
-            atomic_store(&r->job_failed, 1);
-        }
-    }
+    /* the producer lends a hand (and is the only inflater when there is no pool) */
+    if (r->own_inf) inflate_blocks(r, r->own_inf);
+    else if (r->n_workers == 0) atomic_store(&r->job_failed, 1);
     if (r->n_workers > 0) {
         pthread_mutex_lock(&r->job_mu);
         while (r->job_active) pthread_cond_wait(&r->done_cv, &r->job_mu);
@@ -303,11 +291,24 @@ static int parse_header(bam_reader *r, const uint8_t *p, size_t len, int input_d
 /* indexes the whole records of s->buf[s->start .. len); 0 ok / -1 error */
 static int index_slot(bam_reader *r, slot_t *s, size_t len)
 {
-    size_t o = s->start, n = 0;
+    size_t o = s->start, n = 0, stride = 0;
     while (o + 4 <= len) {
         const uint32_t bs = le32(s->buf + o);
         if (bs < 32) { set_err(r, "alignment record with block_size %u < 32", bs); return -1; }
         if (o + 4 + (size_t)bs > len) break;
+        /* The walk is a chain of dependent loads, one cache miss per record.  Records of one
+         * file are of similar size, so the length word PREFETCH_AHEAD records further on is
+         * close to o + AHEAD * (mean record size so far): touching that line and its neighbours
+         * turns most of the misses into hits (a wrong guess costs nothing but the prefetch). */
+        if ((n & 63u) == 0) stride = n ? (o - s->start) / n : 4 + (size_t)bs;
+        {
+            const uint8_t *guess = s->buf + o + PREFETCH_AHEAD * stride;
+            if (guess + 128 < s->buf + len) {
+                __builtin_prefetch(guess - 64, 0, 0);
+                __builtin_prefetch(guess, 0, 0);
+                __builtin_prefetch(guess + 64, 0, 0);
+            }
+        }
         if (n + 2 > s->offs_cap) {
             const size_t cap = s->offs_cap ? s->offs_cap * 2 : (1u << 20);
             uint32_t *no = (uint32_t *)realloc(s->offs, cap * sizeof(uint32_t));
@@ -502,6 +503,7 @@ bam_reader *bam_reader_open(const char *path, int n_threads, size_t batch_bytes,
     }
     for (int w = 0; w < N_SLOTS; w++) r->slot[w].buf = r->ubase + (size_t)w * slot_bytes;
 
+    r->own_inf = (pss_inflater *)malloc(sizeof(pss_inflater));
     /* the producer counts as one inflater */
     for (int t = 0; t < n_threads - 1; t++) {
         if (pthread_create(&r->worker[r->n_workers], NULL, worker_main, r) != 0) break;
@@ -583,6 +585,7 @@ void bam_reader_close(bam_reader *r)
     if (r->fd >= 0) close(r->fd);
     free(r->ubase);
     free(r->blk);
+    free(r->own_inf);
     for (int w = 0; w < N_SLOTS; w++) free(r->slot[w].offs);
     free(r->carry);
     free(r->hdr.text);

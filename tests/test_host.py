@@ -351,6 +351,81 @@ def test_bam_reader_edge_inputs(host, tmp_path):
     assert pr.returncode == 0 and pr.stdout.count("\n") == 3
 
 
+def test_inflate_fast_and_crc_against_zlib(host):
+    """pss_inflate_raw / pss_crc32 (the BGZF decoder of the feed) against zlib: stored, fixed and
+    dynamic blocks from every level/strategy, skewed alphabets (codes longer than the table index),
+    exact-size contract, truncated and bit-flipped streams (no stray writes, never more lenient than
+    zlib on a stream zlib accepts)."""
+    import zlib
+    L, _ = host
+    L.pss_inflate_raw.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    L.pss_inflate_raw.restype = C.c_int
+    L.pss_crc32.argtypes = [C.c_uint32, C.c_char_p, C.c_size_t]
+    L.pss_crc32.restype = C.c_uint32
+    st = C.create_string_buffer(32768)
+    rng = np.random.default_rng(1)
+
+    def raw_deflate(data, level, strategy, memlevel):
+        c = zlib.compressobj(level, zlib.DEFLATED, -15, memlevel, strategy)
+        return c.compress(data) + c.flush()
+
+    def gen(kind, n):
+        if kind == 0:
+            return rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        if kind == 1:
+            return rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), n).tobytes()
+        if kind == 2:
+            return bytes(n)
+        if kind == 3:   # skewed alphabet with rare symbols -> codewords longer than 11 bits
+            p = np.array([2.0 ** -(i * 0.35) for i in range(200)])
+            return rng.choice(np.arange(200, dtype=np.uint8), n, p=p / p.sum()).tobytes()
+        if kind == 4:   # repeats at all distances, runs (distance 1), overlapping copies
+            base = rng.integers(0, 256, 300, dtype=np.uint8).tobytes()
+            out = bytearray()
+            while len(out) < n:
+                k = int(rng.integers(0, 280))
+                out += base[k:k + int(rng.integers(3, 300))]
+                if rng.random() < 0.3:
+                    out += bytes([int(rng.integers(0, 256))]) * int(rng.integers(1, 400))
+            return bytes(out[:n])
+        return b"".join(b"read%07d\t%d\tchr%d\t%d\t37\t100M\t*\t0\t0\n" % (i, i % 5, i % 22, i * 13)
+                        for i in range(n // 40 + 1))[:n]
+
+    strategies = [zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FIXED]
+    for it in range(400):
+        n = int(rng.integers(0, 65536 if it % 3 else 2000))
+        data = gen(int(rng.integers(0, 6)), n)
+        n = len(data)
+        comp = raw_deflate(data, int(rng.integers(0, 10)), strategies[int(rng.integers(0, 5))], int(rng.integers(1, 10)))
+        out = C.create_string_buffer(n + 16)
+        out.raw = b"\xAA" * (n + 16)
+        assert L.pss_inflate_raw(st, comp, len(comp), out, n) == 0, it
+        assert out.raw[:n] == data and out.raw[n:] == b"\xAA" * 16, it
+        assert L.pss_crc32(0, data, n) == zlib.crc32(data)
+        k = int(rng.integers(0, n + 1))
+        assert L.pss_crc32(L.pss_crc32(0, data[:k], k), data[k:], n - k) == zlib.crc32(data)
+        if n:
+            assert L.pss_inflate_raw(st, comp, len(comp), out, n - 1) != 0       # stream longer than promised
+        assert L.pss_inflate_raw(st, comp, len(comp), out, n + 1) != 0           # stream shorter than promised
+        cut = int(rng.integers(0, len(comp)))
+        assert L.pss_inflate_raw(st, comp[:cut], cut, out, n) != 0               # truncated input
+        if len(comp) > 4:
+            b = bytearray(comp)
+            b[int(rng.integers(0, len(b)))] ^= 1 << int(rng.integers(0, 8))
+            rc = L.pss_inflate_raw(st, bytes(b), len(b), out, n)
+            try:
+                d = zlib.decompressobj(-15)
+                z = d.decompress(bytes(b))
+                zok = d.eof and len(z) == n
+            except zlib.error:
+                zok = False
+            if zok:
+                assert rc == 0 and out.raw[:n] == z
+            else:
+                assert rc != 0, "accepted a stream zlib rejects"
+        assert out.raw[n:] == b"\xAA" * 16, "wrote past the end on an error path"
+
+
 def test_front_end_argument_handling(host, tmp_path):
     _, pkg = host
     pss, fk = pkg.PKG_DIR / "bin" / "pss-bam", pkg.PKG_DIR / "bin" / "fragkon"
