@@ -358,10 +358,12 @@ def cpu_all_cores(pkg, synth, scfg, region_len, names, tmp, o, cores, per_shard)
     with ThreadPoolExecutor(min(threads, 32)) as ex:   # the writers release the GIL
         list(ex.map(lambda k: synth.sam_host(scfg, k * per_shard, per_shard, tmp / f"shard{k}.sam"), range(cores)))
 
+    variant = os.environ.get("PSSBAM_REF_VARIANT", "pss-bam.O2")
+
     def wave(inputs, tag):
         t = time.perf_counter()
         with ThreadPoolExecutor(cores) as ex:
-            res = list(ex.map(lambda kv: tl.run_ref_pss(fa, kv[1], tmp / f"{tag}{kv[0]}", o, variant="pss-bam.O2",
+            res = list(ex.map(lambda kv: tl.run_ref_pss(fa, kv[1], tmp / f"{tag}{kv[0]}", o, variant=variant,
                                                         timeout=3000)[:2], enumerate(inputs)))
         return time.perf_counter() - t, res
 
@@ -380,7 +382,7 @@ def cpu_all_cores(pkg, synth, scfg, region_len, names, tmp, o, cores, per_shard)
     e2.close()
     ok = bool(np.array_equal(got.fwd, fwd) and np.array_equal(got.rev, rev))
     return {"value": total / max(t_full - t_load, 1e-9), "unit": "reads/s", "cores": cores,
-            "sample": f"{cores} concurrent oracle/_ref/pss-bam.O2 processes x {per_shard} reads each (consecutive shards of "
+            "sample": f"{cores} concurrent oracle/_ref/{variant} processes x {per_shard} reads each (consecutive shards of "
                       f"the sorted stream, FASTA of contigs 0..{last_contig}); wall {t_full:.1f}s minus {t_load:.1f}s for the "
                       f"same {cores} processes on an empty SAM",
             "parity_check": "summed tables bit-exact vs the engine" if ok else "MISMATCH vs the engine"}

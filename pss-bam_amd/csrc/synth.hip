@@ -154,8 +154,8 @@ int synth_offsets_linear_device(uint32_t *d_offs, uint64_t n_plus_1, uint32_t re
 int synth_sam_host(const synth_cfg *c, uint64_t slot0, uint64_t n, const char *path, int with_header) {
     FILE *f = fopen(path, "w");
     if (!f) return -1;
-    static char iobuf[1 << 20];
-    setvbuf(f, iobuf, _IOFBF, sizeof iobuf);
+    std::vector<char> iobuf(1 << 20);  // per call: the writers may run concurrently
+    setvbuf(f, iobuf.data(), _IOFBF, iobuf.size());
     char nm[16];
     if (with_header) {
         fputs("@HD\tVN:1.6\tSO:unknown\n", f);
@@ -191,8 +191,8 @@ int synth_fasta_host(const synth_cfg *c, const char *path, uint32_t first, uint3
                      int threads) {
     FILE *f = fopen(path, "w");
     if (!f) return -1;
-    static char iobuf[1 << 20];
-    setvbuf(f, iobuf, _IOFBF, sizeof iobuf);
+    std::vector<char> iobuf(1 << 20);  // per call: the writers may run concurrently
+    setvbuf(f, iobuf.data(), _IOFBF, iobuf.size());
     const uint64_t CH = 1u << 24;
     std::vector<uint8_t> buf(CH);
     std::vector<char> line((size_t)CH + CH / width + 2);
