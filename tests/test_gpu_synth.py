@@ -140,3 +140,79 @@ def test_order_invariance_and_additivity_large(env):
     for key, t in tabs.items():
         assert np.array_equal(t.fwd, base.fwd) and np.array_equal(t.rev, base.rev), key
         assert np.array_equal(t.k5, base.k5) and np.array_equal(t.k3, base.k3), key
+
+
+def test_full_size_baseline_config_properties(env):
+    """BASELINE.json's metric configuration at its FULL size (C3: 200 M x 150 bp reads, 3.1 Gb
+    24-contig reference, N=25, k=4), where no CPU oracle finishes in reasonable time.  Checked
+    through properties that do not depend on the size:
+      (a) order invariance: the shuffled stream is a permutation of the sorted one -> same tables;
+      (b) additivity: four contiguous 50 M-read shards tallied by four engines (what four ranks
+          do) and summed == one engine over everything;
+      (c) the two kernels (tiled production kernel, generic lane-per-read kernel) agree;
+      (d) bookkeeping: every record is accounted for exactly once in the status counters, each
+          table row holds at most one count per tallied read, and the two context rows of a
+          table agree with each other up to non-ACGT reference bases (<= 1 %)."""
+    pkg, synth = env
+    dev = torch.device("cuda", 0)
+    S = synth.lib()
+    stream = torch.cuda.current_stream().cuda_stream
+    n_total, n_block, n_shards = 200_000_000, 12_500_000, 4
+    cfgs = {}
+    for srt in (True, False):
+        d = synth.config("C3", sorted_=srt)
+        region_len = d.pop("region_len")
+        d.pop("klen", None)
+        assert d["n_reads"] == n_total
+        cfgs[srt] = synth.make_cfg(**d)
+    cfg = cfgs[True]
+    names = [synth.contig_name(cfg, k) for k in range(int(cfg.n_contigs))]
+    contigs = []
+    for k in range(int(cfg.n_contigs)):
+        ln = int(cfg.contig_len[k])
+        t = torch.empty(ln + 64, dtype=torch.uint8, device=dev)
+        assert S.synth_genome_device(C.byref(cfg), k, t.data_ptr(), ln, stream) == 0
+        contigs.append(t)
+
+    def engine(kernel=0):
+        e = pkg.Engine(pss=dict(region_len=region_len), kmer=dict(klen=4), kernel=kernel)
+        e.set_stream(stream)
+        e.set_genome_device([(names[k], contigs[k].data_ptr(), int(cfg.contig_len[k])) for k in range(len(names))])
+        e.set_references(names)
+        return e
+
+    e_sorted, e_shuffled, e_simple = engine(pkg.KERNEL_TILED), engine(pkg.KERNEL_TILED), engine(pkg.KERNEL_SIMPLE)
+    e_shard = [engine() for _ in range(n_shards)]
+    del contigs
+    rec_bytes = int(synth.sizes_host(cfg, 0, 1)[0])
+    rt = torch.empty(n_block * rec_bytes + 64, dtype=torch.uint8, device=dev)
+    ot = torch.empty(n_block + 1, dtype=torch.int32, device=dev)
+    assert S.synth_offsets_linear_device(ot.data_ptr(), n_block + 1, rec_bytes, stream) == 0
+    for srt in (True, False):
+        for a in range(0, n_total, n_block):
+            assert S.synth_records_device(C.byref(cfgs[srt]), a, n_block, ot.data_ptr(), rt.data_ptr(), stream) == 0
+            targets = [e_sorted, e_simple, e_shard[a // (n_total // n_shards)]] if srt else [e_shuffled]
+            for e in targets:
+                e.submit_device(rt.data_ptr(), n_block * rec_bytes, ot.data_ptr(), n_block)
+            torch.cuda.synchronize()   # the block buffer is regenerated next
+    base = e_sorted.finish()
+    shuf, simple = e_shuffled.finish(), e_simple.finish()
+    parts = [e.finish() for e in e_shard]
+    for e in [e_sorted, e_shuffled, e_simple] + e_shard:
+        e.close()
+
+    for other, what in ((shuf, "shuffled order"), (simple, "generic kernel")):
+        for f in ("fwd", "rev", "k5", "k3"):
+            assert np.array_equal(getattr(other, f), getattr(base, f)), (what, f)
+    for f in ("fwd", "rev", "k5", "k3"):
+        assert np.array_equal(sum(getattr(p, f).astype(np.uint64) for p in parts), getattr(base, f).astype(np.uint64)), f
+    st = base.stats
+    assert st["records"] == n_total and sum(p.stats["records"] for p in parts) == n_total
+    assert st["pss_ok"] + st["pss_filtered"] + st["no_contig"] + st["parse_skip"] == n_total
+    assert st["slow_path"] == 0 and shuf.stats == st
+    assert 0.98 * n_total < st["pss_ok"] <= n_total
+    for tab in (base.fwd, base.rev):
+        rows = tab.reshape(region_len + 2, 16).sum(axis=1)
+        assert rows.max() <= st["pss_ok"] and rows.min() >= 0.97 * st["pss_ok"]
+        assert abs(int(rows[0]) - int(rows[1])) <= 0.01 * st["pss_ok"]
+    assert int(base.k5.sum()) <= st["kmer_ok"] + st["kmer_fail"] and int(base.k5.sum()) >= 0.97 * n_total
