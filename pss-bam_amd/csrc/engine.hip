@@ -107,6 +107,7 @@ struct pssbam_engine {
     uint64_t kernel_launches = 0;
     // tuning overrides (environment, for experiments)
     int env_tile_reads = 0, env_grid_mult = 0, env_simple_blocks = 0, env_grid_wgs = 0, env_pieces = 0;
+    bool warned_ablate = false;
     uint32_t prep_lds[8] = {0};     // prep_kernel's memo, by kernel variant
     int prep_occ[8] = {0};
     uint32_t *d_scratch = nullptr;  // per-workgroup partial tables of the tiled kernel
@@ -489,7 +490,11 @@ static int launch_tally(pssbam_engine *e, const uint8_t *d_recs, uint64_t nbytes
         if (e->env_tile_reads > 0) T = std::min<uint32_t>(TILED_MAX_T, (uint32_t)(e->env_tile_reads + 15) / 16 * 16);
         P.reads_per_tile = T;
         P.prefix_pieces = pieces;
-        P.ablate = (uint32_t)env_int("PSSBAM_ABLATE");
+        P.ablate = (uint32_t)env_int("PSSBAM_ABLATE");  // profiling aid (tools/ablate.sh): switches kernel phases off
+        if (P.ablate && !e->warned_ablate) {
+            fprintf(stderr, "[pssbam] PSSBAM_ABLATE=%u: kernel phases are switched off, the tables are WRONG (profiling only)\n", P.ablate);
+            e->warned_ablate = true;
+        }
         const bool kmer_lds = do_kmer && c.kmer.klen <= KMER_LDS_MAX_K;
         const uint32_t n_tiles = (n_records + T - 1) / T;
         const uint32_t lds = tiled_lds_bytes(T, pieces);

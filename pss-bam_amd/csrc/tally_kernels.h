@@ -11,25 +11,29 @@
 //                              wave-instruction contiguously in LDS -- so record j's first
 //                              P*16 bytes (header, name, CIGAR, SEQ, QUAL[0]: everything the
 //                              path reads) land densely at stage + j*P*16.  The ~150 QUAL bytes
-//                              of a 150-bp record are never fetched: HBM traffic is BELOW the
-//                              record size, the staging buffer is half of a whole-record tile,
-//                              and consecutive lanes still read consecutive addresses (cheap
+//                              of a 150-bp record are never requested: the staging buffer is
+//                              half of a whole-record tile (4 workgroups per CU instead of 3)
+//                              and half the DMA issue slots are saved -- HBM itself still moves
+//                              whole 128-byte lines, so its traffic stays close to the record
+//                              size -- and consecutive lanes read consecutive addresses (cheap
 //                              for the texture addresser).  The next tile's DMA is issued as
 //                              soon as CODES-A is done with the buffer.
 //                   2. CODES   a lane pair per read (one lane per alignment end).  Part A:
 //                              decode + filters from LDS, the end's reference window
 //                              (32 bytes) and k-mer window gathered from the device genome,
 //                              SEQ nibbles into registers.  Part B: one byte per window
-//                              position = (cell << 1 | table) or CODE_NONE through a 272-byte
-//                              LDS lookup table indexed by (read nibble, reference code,
-//                              strand), written as the read's row of the code sheet.
+//                              position = (cell << 1 | table) or a "no count" code, four
+//                              positions per VALU instruction through v_perm_b32 used as a
+//                              byte table (no memory lookups), written as the read's row of
+//                              the code sheet.
 //                   3. COLUMNS wave-per-read, lane = column of the code sheet: each lane
 //                              owns one (end, position) and bumps ITS word of a
 //                              [cell,table][row] LDS table.  Lanes of one wave-instruction
 //                              never share a word and the two 32-lane halves hit disjoint
 //                              banks, so the AA/CC/GG/TT skew of real data causes no
 //                              serialisation at all.
-//                 Counters leave LDS once, at kernel end, as u64 global atomics.
+//                 Counters leave LDS once, at kernel end, as plain stores into the workgroup's
+//                 slot of a scratch buffer; reduce_partials sums the slots into the u64 block.
 //
 // Integer/byte work only: no MFMA anywhere (the bound is HBM bandwidth).
 #pragma once
@@ -420,7 +424,7 @@ __device__ __forceinline__ void tally_tiled_body(const TallyParams &P, const Tal
             if (next + tstride < n_tiles) load_offsets(next + tstride);
         }
 
-        // ---- CODES, part B: registers + genome + LUT only ------------------------------------------
+        // ---- CODES, part B: registers only ------------------------------------------------------------
         {
             // first context base next to the alignment: left window byte 1 (s-1), right window byte 30 (s+L)
             const uint32_t own1 = e ? (gw[7] >> 16) & 0xFFu : (gw[0] >> 8) & 0xFFu;
