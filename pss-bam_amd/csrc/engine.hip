@@ -79,6 +79,8 @@ struct pssbam_engine {
 
     // genome
     uint8_t *d_genome = nullptr;
+    uint32_t *d_genome4 = nullptr;  // 4-bit image for the tiled kernel's window gathers
+    uint32_t acgt_ctx = 0;
     uint64_t genome_bytes = 0;
     std::vector<uint64_t> contig_start;  // per sorted contig
     std::vector<uint32_t> contig_len;
@@ -223,6 +225,7 @@ extern "C" void pssbam_engine_destroy(pssbam_engine *e) {
     if (e->t_end) (void)hipEventDestroy(e->t_end);
     if (e->d_scratch) (void)hipFree(e->d_scratch);
     if (e->d_genome) (void)hipFree(e->d_genome);
+    if (e->d_genome4) (void)hipFree(e->d_genome4);
     if (e->d_ref_info) (void)hipFree(e->d_ref_info);
     if (e->d_rg) (void)hipFree(e->d_rg);
     if (e->d_counters_own) (void)hipFree(e->d_counters_own);
@@ -280,6 +283,21 @@ extern "C" int pssbam_engine_set_genome_arrays(pssbam_engine *e, size_t n, const
     // raw bytes (and NUL padding) are in place: one pass folds case and applies enc_byte to all
     hipLaunchKernelGGL(encode_genome_kernel, dim3(4096), dim3(256), 0, e->stream, e->d_genome, total / 16);
     HIP_TRY(hipGetLastError());
+    if (e->d_genome4) { HIP_TRY(hipFree(e->d_genome4)); e->d_genome4 = nullptr; }
+    {
+        // 4 bits per base for the tiled kernel's windows: A C G T, or "other" with its -U / -D membership
+        CtxSets sets;
+        ctx_mask(e->up_ctx.c_str(), sets.up);
+        ctx_mask(e->down_ctx.c_str(), sets.down);
+        e->acgt_ctx = 0;
+        for (uint32_t v = 0; v < 4; v++)
+            e->acgt_ctx |= (((sets.up[0] >> v) & 1u) << (2 * v)) | (((sets.down[0] >> v) & 1u) << (2 * v + 1));
+        const uint64_t n_out = total / 8, slack = 16;
+        HIP_TRY(hipMalloc(&e->d_genome4, (n_out + slack) * sizeof(uint32_t)));
+        HIP_TRY(hipMemsetAsync(e->d_genome4 + n_out, 0x44, slack * sizeof(uint32_t), e->stream));
+        hipLaunchKernelGGL(pack_genome4_kernel, dim3(4096), dim3(256), 0, e->stream, e->d_genome, e->d_genome4, n_out, sets);
+        HIP_TRY(hipGetLastError());
+    }
     e->contig_start.assign(start.begin(), start.begin() + n);
     e->contig_len.assign(len.begin(), len.begin() + n);
     HIP_TRY(hipStreamSynchronize(e->stream));
@@ -421,6 +439,8 @@ static int launch_tally(pssbam_engine *e, const uint8_t *d_recs, uint64_t nbytes
     P.recs_bytes = nbytes;
     P.tally_mask = c.tally_mask;
     P.genome = e->d_genome;
+    P.genome4 = e->d_genome4;
+    P.acgt_ctx = e->acgt_ctx;
     P.ref_info = e->d_ref_info;
     P.n_ref = e->n_ref;
     const bool do_pss = (c.tally_mask & PSSBAM_TALLY_PSS) != 0, do_kmer = (c.tally_mask & PSSBAM_TALLY_KMER) != 0;

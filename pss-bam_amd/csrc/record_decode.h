@@ -33,6 +33,10 @@ struct TallyParams {
     uint64_t recs_bytes;          // bytes of the record block (= offs[n_recs])
     uint32_t tally_mask;          // PSSBAM_TALLY_*
     const uint8_t *genome;        // all contigs, 1 stored byte/base (enc_byte), padded between
+    // the same array at 4 bits/base for the tiled kernel's end windows (half the HBM lines):
+    // position p = bits 4*(p%8) of dword p/8; nibble 0..3 = A C G T, 4 + (in -U) + 2*(in -D) otherwise
+    const uint32_t *genome4;
+    uint32_t acgt_ctx;            // bit 2v: base v in -U, bit 2v+1: in -D (v = 0..3 for A C G T)
     // BAM refID -> where its contig lies, resolved once per header by find_seq semantics:
     // ref_info[refID] = {gbase lo, gbase hi, contig length, found ? 1 : 0}; entry n_ref is the
     // one for RNAME "*" (refID -1; found only if a contig is literally named "*")
@@ -387,6 +391,19 @@ __device__ __forceinline__ void plan_finish_pss(const Ctx &ctx, Plan &pl, uint32
     const bool r1 = (pl.flag & FL_READ1) != 0, r2 = (pl.flag & FL_READ2) != 0;
     // unpaired: both tables, both tests (:428-447); paired: read1 && up -> fwd only, else
     // read2 && down -> rev only (:450-494)
+    pl.pss_fwd = pl.pss_cand && (paired ? (r1 && up_ok) : (up_ok && dn_ok));
+    pl.pss_rev = pl.pss_cand && (paired ? (!(r1 && up_ok) && r2 && dn_ok) : (up_ok && dn_ok));
+}
+
+// The same decision from the packed reference's nibbles (tiled kernel): an "other" nibble carries
+// its own -U / -D membership, complementing leaves it unchanged (do_revcomp copies non-ACGT bytes).
+__device__ __forceinline__ void plan_finish_pss_packed(uint32_t acgt_ctx, Plan &pl, uint32_t left1, uint32_t right1) {
+    const uint32_t up = pl.rev ? (right1 < 4u ? 3u - right1 : right1) : left1;
+    const uint32_t dn = pl.rev ? (left1 < 4u ? 3u - left1 : left1) : right1;
+    const bool up_ok = ((up < 4u ? acgt_ctx >> (2u * up) : up) & 1u) != 0;
+    const bool dn_ok = ((dn < 4u ? acgt_ctx >> (2u * dn + 1u) : dn >> 1) & 1u) != 0;
+    const bool paired = (pl.flag & FL_PAIRED) != 0;
+    const bool r1 = (pl.flag & FL_READ1) != 0, r2 = (pl.flag & FL_READ2) != 0;
     pl.pss_fwd = pl.pss_cand && (paired ? (r1 && up_ok) : (up_ok && dn_ok));
     pl.pss_rev = pl.pss_cand && (paired ? (!(r1 && up_ok) && r2 && dn_ok) : (up_ok && dn_ok));
 }

@@ -45,7 +45,6 @@ namespace pssbam {
 constexpr int TILED_THREADS = 256;
 constexpr int TILED_WAVES = TILED_THREADS / 64;
 constexpr int TILED_MAX_N = 30;        // N+2 positions per end must fit 32 lanes
-constexpr int WIN_DWORDS = 9;          // 32 window bytes + 3 alignment bytes <= 36
 constexpr int KMER_LDS_MAX_K = 4;      // 2 * 4^4 * 4 B = 2 KiB of LDS
 constexpr uint32_t STAGE_SLACK = 64;   // readable bytes behind a staging buffer
 constexpr uint32_t CODE_NONE = 32;     // sheet byte meaning "no count"; every code >= 32 is one
@@ -197,6 +196,7 @@ __host__ __device__ inline uint32_t tiled_lds_bytes(uint32_t T, uint32_t pieces)
 // wave-instruction and per distinct line touched -- nine single-dword gathers of a 36-byte
 // window cost three times what 2 x dwordx4 + 1 x dword do.
 struct __attribute__((packed, aligned(4))) Quad { uint32_t v[4]; };
+struct __attribute__((packed, aligned(4))) Tri { uint32_t v[3]; };
 
 constexpr uint32_t TILED_MAX_T = 128;
 static_assert(TILED_MAX_T * 2 == TILED_THREADS, "CODES maps one (read, end) pair to each thread");
@@ -347,20 +347,20 @@ __device__ __forceinline__ void tally_tiled_body(const TallyParams &P, const Tal
         // this end's reference window, issued for every candidate before the -U/-D test so the
         // test costs no extra memory round trip
         const bool cand = DO_PSS && pl.pss_cand;
-        uint32_t gw[WIN_DWORDS];
-#pragma unroll
-        for (int k = 0; k < WIN_DWORDS; k++) gw[k] = 0u;
+        // 32 window positions = 16 bytes of the 4-bit packed reference (+ up to 7 nibbles of
+        // misalignment): five dwords, one dwordx4 + one dword gather
+        uint32_t gq[5] = {0u, 0u, 0u, 0u, 0u};
         uint32_t gsh = 0u;
         if (cand) {
             const uint64_t ga = pl.gbase + (uint64_t)pl.s + (e ? (uint64_t)pl.L - 30ull : (uint64_t)-2ll);
-            const uint32_t *pg = (const uint32_t *)(P.genome + (ga & ~3ull));
+            const uint32_t *pg = P.genome4 + (ga >> 3);
             if (!(ablate & 128u)) {
-                const Quad q0 = *(const Quad *)pg, q1 = *(const Quad *)(pg + 4);
+                const Quad q0 = *(const Quad *)pg;
 #pragma unroll
-                for (int k = 0; k < 4; k++) { gw[k] = q0.v[k]; gw[4 + k] = q1.v[k]; }
-                gw[8] = pg[8];
+                for (int k = 0; k < 4; k++) gq[k] = q0.v[k];
+                gq[4] = pg[4];
             }
-            gsh = (uint32_t)(ga & 3ull);
+            gsh = 4u * (uint32_t)(ga & 7ull);
         }
         // read bases of this end as a nibble stream aligned with the window bytes: stream nibble
         // b <-> read base n0 + b, n0 = -2 (left: bytes 0,1 are context, their nibbles are never
@@ -382,17 +382,16 @@ __device__ __forceinline__ void tally_tiled_body(const TallyParams &P, const Tal
         // of a reverse read), the right-end lane the one at ..s+L+k/2 (fragkon.c:152-181)
         const uint32_t kwhich = e ^ (pl.rev ? 1u : 0u);  // 0 = 5' table, 1 = 3' table
         const bool kmer_try = DO_KMER && (kwhich ? pl.fk3 : pl.fk5) && !(ablate & 16u);
-        uint32_t kw[4] = {0u, 0u, 0u, 0u};
+        uint32_t kw[3] = {0u, 0u, 0u};
         uint32_t ksh = 0u;
         if (kmer_try) {
             int64_t w5, w3;
             kmer_windows(pl, P.K, w5, w3);
             const uint64_t ka = pl.gbase + (uint64_t)(kwhich ? w3 : w5);
-            const uint32_t *pk = (const uint32_t *)(P.genome + (ka & ~3ull));
-            const Quad kq = *(const Quad *)pk;  // 12 window bytes at any alignment, one gather
+            const Tri kq = *(const Tri *)(P.genome4 + (ka >> 3));  // 12 window nibbles at any alignment, one gather
 #pragma unroll
-            for (int k = 0; k < 4; k++) kw[k] = kq.v[k];
-            ksh = (uint32_t)(ka & 3ull);
+            for (int k = 0; k < 3; k++) kw[k] = kq.v[k];
+            ksh = 4u * (uint32_t)(ka & 7ull);
         }
         uint32_t ev_over = 0u;  // events of a record handled by the out-of-line path
         if (in_tile && !in_stage && e == 0u) {
@@ -403,16 +402,17 @@ __device__ __forceinline__ void tally_tiled_body(const TallyParams &P, const Tal
         // vmcnt retires in order and hipcc's counted wait for these loads cannot see the
         // asm-issued DMA pieces, so a wait placed after the DMA issue would also wait for the
         // whole transfer and serialise it against CODES-B / COLUMNS.
+        uint32_t W[4];  // nibble q of W[m] = window position 8m + q
 #pragma unroll
-        for (int k = 0; k < WIN_DWORDS - 1; k++) gw[k] = __builtin_amdgcn_alignbyte(gw[k + 1], gw[k], gsh);
+        for (int m = 0; m < 4; m++) W[m] = __builtin_amdgcn_alignbit(gq[m + 1], gq[m], gsh);
 #pragma unroll
-        for (int k = 0; k < 3; k++) kw[k] = __builtin_amdgcn_alignbyte(kw[k + 1], kw[k], ksh);
+        for (int k = 0; k < 2; k++) kw[k] = __builtin_amdgcn_alignbit(kw[k + 1], kw[k], ksh);
         // pin those uses here (the scheduler would otherwise sink them below the DMA issue)
 #pragma unroll
-        for (int k = 0; k < WIN_DWORDS - 1; k++) asm volatile("" : "+v"(gw[k]));
+        for (int m = 0; m < 4; m++) asm volatile("" : "+v"(W[m]));
         if (DO_KMER) {
 #pragma unroll
-            for (int k = 0; k < 3; k++) asm volatile("" : "+v"(kw[k]));
+            for (int k = 0; k < 2; k++) asm volatile("" : "+v"(kw[k]));
         }
         __syncthreads();
 
@@ -426,10 +426,10 @@ __device__ __forceinline__ void tally_tiled_body(const TallyParams &P, const Tal
 
         // ---- CODES, part B: registers only ------------------------------------------------------------
         {
-            // first context base next to the alignment: left window byte 1 (s-1), right window byte 30 (s+L)
-            const uint32_t own1 = e ? (gw[7] >> 16) & 0xFFu : (gw[0] >> 8) & 0xFFu;
+            // first context base next to the alignment: left window position 1 (s-1), right position 30 (s+L)
+            const uint32_t own1 = e ? (W[3] >> 24) & 15u : (W[0] >> 4) & 15u;
             const uint32_t other1 = (uint32_t)__shfl_xor((int)own1, 1);
-            if (DO_PSS) plan_finish_pss(CtxLds{ctxf}, pl, e ? other1 : own1, e ? own1 : other1);
+            if (DO_PSS) plan_finish_pss_packed(P.acgt_ctx, pl, e ? other1 : own1, e ? own1 : other1);
             uint32_t code_w[8];
 #pragma unroll
             for (int k = 0; k < 8; k++) code_w[k] = CODE_NONE * 0x01010101u;
@@ -444,36 +444,35 @@ __device__ __forceinline__ void tally_tiled_body(const TallyParams &P, const Tal
                 //               lands on 0xFF (pool filler, sign replicas of bytes 1,3,5,7, or >= 13);
                 //               value = (3 - idx) << 3  (complemented: T must be 0), A carries 0x80 so
                 //               that selector 10 (nibble 14) replicates a set sign bit
-                //   reference : selector = stored byte with 12 bumped to 13 (12 would read as 0x00);
-                //               pool: [0..3] = (3 - idx) << 1, C and T carry 0x80 (selectors 8, 9)
+                //   reference : selector = the packed reference's nibble: 0..3 = A C G T, 4..7 = "other"
+                //               pool: [0..3] = (3 - idx) << 1, [4..7] = 0xFF
                 // OR of the two = (15 - cell) << 1, the reverse-strand code; forward-strand lanes XOR
                 // 0x1E to get cell << 1.  Anything invalid is 0xFF and ends, after the final & 0x3F,
                 // on code 33 or 63: rows >= 32 of the count table are the trash bin.
+                // Both nibble streams are split into EVEN and ODD positions (byte i of E[m] / O[m] =
+                // position 8m + 2i / 8m + 2i + 1); the code sheet row keeps that order, see COLUMNS.
                 uint32_t S[5];
 #pragma unroll
                 for (int k = 0; k < 5; k++) S[k] = __builtin_amdgcn_alignbyte(rr[k + 1], rr[k], ssh);
-                // stream byte i holds positions 2i (high nibble), 2i+1 (low nibble) when n0 is even;
+                // SEQ byte i holds positions 2i (high nibble), 2i+1 (low nibble) when n0 is even;
                 // when n0 is odd position 2i is the LOW nibble of byte i and 2i+1 the HIGH nibble of
                 // byte i+1
                 const bool odd = (n0 & 1) != 0;
                 const uint32_t M = 0x0F0F0F0Fu;
-                uint32_t nb[8];
+                const uint32_t sx = pl.rev ? 0u : 0x1E1E1E1Eu;
+                const uint32_t tsel4 = tsel * 0x01010101u;
+                uint32_t RE[4], RO[4], GE[4], GO[4];
 #pragma unroll
                 for (int m = 0; m < 4; m++) {
                     const uint32_t S1 = __builtin_amdgcn_alignbyte(S[m + 1], S[m], 1);
                     const uint32_t A = odd ? S1 : S[m];
                     const uint32_t hiA = (A >> 4) & M, loS = S[m] & M;
-                    const uint32_t E = odd ? loS : hiA, O = odd ? hiA : loS;  // even / odd positions
-                    nb[2 * m] = __builtin_amdgcn_perm(O, E, 0x05010400u);      // positions 8m .. 8m+3
-                    nb[2 * m + 1] = __builtin_amdgcn_perm(O, E, 0x07030602u);  // positions 8m+4 .. 8m+7
-                }
-                const uint32_t sx = pl.rev ? 0u : 0x1E1E1E1Eu;
-                const uint32_t tsel4 = tsel * 0x01010101u;
-                uint32_t Rl[8], Gl[8];
-#pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    Rl[k] = __builtin_amdgcn_perm(0xFF1098FFu, 0xFFFFFF08u, nb[k] ^ 0x04040404u);
-                    Gl[k] = __builtin_amdgcn_perm(0xFFFFFFFFu, 0x80028406u, gw[k] | ((gw[k] >> 3) & 0x01010101u));
+                    const uint32_t E = odd ? loS : hiA, O = odd ? hiA : loS;
+                    RE[m] = __builtin_amdgcn_perm(0xFF1098FFu, 0xFFFFFF08u, E ^ 0x04040404u);
+                    RO[m] = __builtin_amdgcn_perm(0xFF1098FFu, 0xFFFFFF08u, O ^ 0x04040404u);
+                    // the packed reference is little-endian in nibbles: even positions are the low ones
+                    GE[m] = __builtin_amdgcn_perm(0xFFFFFFFFu, 0x00020406u, W[m] & M);
+                    GO[m] = __builtin_amdgcn_perm(0xFFFFFFFFu, 0x00020406u, (W[m] >> 4) & M);
                 }
                 // bases at or beyond l_seq do not exist (precondition P3): blank them.  Rare (reads
                 // shorter than the window), so the whole wave skips it when no lane needs it.
@@ -481,22 +480,29 @@ __device__ __forceinline__ void tally_tiled_body(const TallyParams &P, const Tal
                 const uint32_t have = have_s <= 0 ? 0u : have_s >= 32 ? 32u : (uint32_t)have_s;
                 if (__any(have < (e ? 30u : 32u))) {
 #pragma unroll
-                    for (int k = 0; k < 8; k++) {
-                        const uint32_t lo = 4u * k;
-                        const uint32_t keep = have >= lo + 4u ? 0xFFFFFFFFu : have > lo ? ((1u << (8u * (have - lo))) - 1u) : 0u;
-                        Rl[k] |= ~keep;
+                    for (int m = 0; m < 4; m++) {
+                        // bytes i of E[m] with 8m + 2i < have, of O[m] with 8m + 2i + 1 < have
+                        const uint32_t left = have > 8u * m ? have - 8u * m : 0u;
+                        const uint32_t ne = min((left + 1u) >> 1, 4u), no = min(left >> 1, 4u);
+                        RE[m] |= ne >= 4u ? 0u : ~((1u << (8u * ne)) - 1u);
+                        RO[m] |= no >= 4u ? 0u : ~((1u << (8u * no)) - 1u);
                     }
                 }
                 // context positions carry no read base: their cell is the diagonal one of their own
-                // reference base (pss-bam.c:172-184).  Left: bytes 0,1; right: bytes 30,31.
+                // reference base (pss-bam.c:172-184).  Left: positions 0,1 = byte 0 of E[0], O[0];
+                // right: positions 30,31 = byte 3 of E[3], O[3].
                 {
-                    const uint32_t d0 = (Gl[0] & 0x06060606u) << 2, d7 = (Gl[7] & 0x06060606u) << 2;
-                    const uint32_t m0 = e ? 0u : 0x0000FFFFu, m7 = e ? 0xFFFF0000u : 0u;
-                    Rl[0] = (Rl[0] & ~m0) | (d0 & m0);
-                    Rl[7] = (Rl[7] & ~m7) | (d7 & m7);
+                    const uint32_t ml = e ? 0u : 0x000000FFu, mr = e ? 0xFF000000u : 0u;
+                    RE[0] = (RE[0] & ~ml) | ((GE[0] << 2) & ml & 0x18181818u);
+                    RO[0] = (RO[0] & ~ml) | ((GO[0] << 2) & ml & 0x18181818u);
+                    RE[3] = (RE[3] & ~mr) | ((GE[3] << 2) & mr & 0x18181818u);
+                    RO[3] = (RO[3] & ~mr) | ((GO[3] << 2) & mr & 0x18181818u);
                 }
 #pragma unroll
-                for (int k = 0; k < 8; k++) code_w[k] = ((Rl[k] | Gl[k] | tsel4) ^ sx) & 0x3F3F3F3Fu;
+                for (int m = 0; m < 4; m++) {
+                    code_w[2 * m] = ((RE[m] | GE[m] | tsel4) ^ sx) & 0x3F3F3F3Fu;
+                    code_w[2 * m + 1] = ((RO[m] | GO[m] | tsel4) ^ sx) & 0x3F3F3F3Fu;
+                }
             }
             bool kmer_ok = true;
             if (kmer_try) {
@@ -506,7 +512,7 @@ __device__ __forceinline__ void tally_tiled_body(const TallyParams &P, const Tal
 #pragma unroll
                 for (int t = 0; t < 12; t++) {
                     if (t < P.K) {
-                        const uint32_t c = (kw[t >> 2] >> (8 * (t & 3))) & 0xFFu;
+                        const uint32_t c = (kw[t >> 3] >> (4 * (t & 7))) & 0xFu;
                         bad |= c & ~3u;
                         bin = pl.rev ? (bin | ((3u - (c & 3u)) << (2 * t))) : ((bin << 2) | (c & 3u));
                     }
@@ -535,8 +541,10 @@ __device__ __forceinline__ void tally_tiled_body(const TallyParams &P, const Tal
 
         // ---- COLUMNS: wave-per-read, lane = (end, window byte) -----------------------------------
         if (DO_PSS && !(ablate & 1u)) {
+            // sheet byte b of an end holds window position 8*(b/8) + 2*(b%4) + (b/4)%2 (even/odd split)
             const uint32_t e = lane >> 5, b = lane & 31u;
-            const uint32_t row = e ? 31u - b : b;
+            const uint32_t wpos = (b & 24u) + 2u * (b & 3u) + ((b >> 2) & 1u);
+            const uint32_t row = e ? 31u - wpos : wpos;
             const uint32_t per_wave = (count + TILED_WAVES - 1u) / TILED_WAVES;
             const uint32_t j0 = wave * per_wave, j1 = min(count, j0 + per_wave);
             if (row < n_pos) {  // (lanes of dead rows would only ever see CODE_NONE)
@@ -686,6 +694,25 @@ __global__ void encode_genome_kernel(uint8_t *p, uint64_t n16) {
             w[k] = o;
         }
         q[i] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+// The tiled kernel's 4-bit image of the stored genome (record_decode.h, TallyParams::genome4):
+// one output dword = 8 consecutive positions, little-endian in nibbles.
+struct CtxSets { uint32_t up[8], down[8]; };
+__global__ void pack_genome4_kernel(const uint8_t *g, uint32_t *out, uint64_t n_out, CtxSets sets) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint2 *src = (const uint2 *)g;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_out; i += stride) {
+        const uint2 v = src[i];
+        uint32_t o = 0u;
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const uint32_t c = ((b < 4 ? v.x : v.y) >> (8 * (b & 3))) & 0xFFu;
+            const uint32_t nib = c < 4u ? c : 4u + (in_set(sets.up, c) ? 1u : 0u) + (in_set(sets.down, c) ? 2u : 0u);
+            o |= nib << (4 * b);
+        }
+        out[i] = o;
     }
 }
 
