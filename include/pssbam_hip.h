@@ -103,6 +103,10 @@ enum {
 
 const char *pssbam_last_error(void);      /* thread-local, never NULL                    */
 int pssbam_device_count(void);            /* number of usable gfx950 devices, 0 if none  */
+/* Optional: brings the HIP runtime and the device's context up (tens of ms) so that a caller
+ * can overlap it with its own start-up work, e.g. from a helper thread while the FASTA loads
+ * (nothing in the reference corresponds; pssbam_engine_create does it otherwise). */
+int pssbam_warmup(int device);
 
 int pssbam_engine_create(const pssbam_config *cfg, pssbam_engine **out);
 void pssbam_engine_destroy(pssbam_engine *e);

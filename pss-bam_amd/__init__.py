@@ -30,7 +30,7 @@ ST_N = 16
 
 # every symbol include/pssbam_hip.h declares (checked by tests/test_cabi.py)
 HIP_SYMBOLS = [
-    "pssbam_last_error", "pssbam_device_count", "pssbam_engine_create", "pssbam_engine_destroy",
+    "pssbam_last_error", "pssbam_device_count", "pssbam_warmup", "pssbam_engine_create", "pssbam_engine_destroy",
     "pssbam_engine_set_stream", "pssbam_engine_set_genome", "pssbam_engine_set_genome_arrays",
     "pssbam_engine_set_references", "pssbam_engine_submit", "pssbam_engine_submit_device", "pssbam_engine_sync",
     "pssbam_engine_finish", "pssbam_engine_reset", "pssbam_engine_counters_device", "pssbam_engine_bind_counters",

@@ -56,6 +56,12 @@ extern "C" int pssbam_device_count(void) {
     return ok;
 }
 
+extern "C" int pssbam_warmup(int device) {
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipFree(nullptr));  // forces the context
+    return PSSBAM_OK;
+}
+
 // --------------------------------------------------------------------------------------
 // engine
 // --------------------------------------------------------------------------------------

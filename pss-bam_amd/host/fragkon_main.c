@@ -71,6 +71,7 @@ int main(int argc, char *argv[])
         fprintf(stderr, "    *** k is odd - counting %d bases outside %d bases inside of alignment.\n", klen / 2,
                 klen / 2 + 1);
     fprintf(stderr, "Reading genome sequence from: %s\n", fasta_fn);
+    frontend_warmup_start();   /* HIP start-up overlaps the FASTA load */
     Genome *genome = init_genome(fasta_fn);
     if (!genome) {
         fprintf(stderr, "Error: Unable to load genome from %s.\n", fasta_fn);
@@ -91,6 +92,7 @@ int main(int argc, char *argv[])
     cfg.kernel = PSSBAM_KERNEL_AUTO;
 
     run_result res;
+    frontend_fast_exit = getenv("PSSBAM_CLEAN_EXIT") == NULL;
     if (run_tally(&cfg, genome, bam_fn, env_gpu_count(), &res)) exit(1);
     fragkon_write_table(stdout, fasta_fn, bam_fn, klen, res.k5, res.k3);
     fflush(stdout);
@@ -99,6 +101,10 @@ int main(int argc, char *argv[])
                 (unsigned long long)res.stats[PSSBAM_ST_RECORDS], (unsigned long long)res.stats[PSSBAM_ST_KMER_OK],
                 (unsigned long long)res.stats[PSSBAM_ST_KMER_FILTERED], (unsigned long long)res.stats[PSSBAM_ST_KMER_FAIL],
                 res.n_gpus);
+    }
+    if (frontend_fast_exit) { /* nothing left to do but to hand the memory back: let the OS */
+        fprintf(stderr, "Done.\n");
+        front_end_exit(0);
     }
     run_result_free(&res);
     destroy_genome(genome);

@@ -8,13 +8,39 @@
  */
 #include "frontend.h"
 
+#include <pthread.h>
+#include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <unistd.h>
 
 #include "bam_reader.h"
 #include "sam_reader.h"
+
+int frontend_fast_exit = 0;
+
+static void *warmup_main(void *arg)
+{
+    (void)arg;
+    const int n = env_gpu_count(); /* the first HIP call: runtime start-up happens here */
+    for (int g = 0; g < n; g++) (void)pssbam_warmup(g); /* failures surface in pssbam_engine_create */
+    return NULL;
+}
+
+void frontend_warmup_start(void)
+{
+    pthread_t th;
+    if (pthread_create(&th, NULL, warmup_main, NULL) == 0) pthread_detach(th);
+}
+
+void front_end_exit(int status)
+{
+    fflush(NULL);
+    if (frontend_fast_exit) _exit(status);
+    exit(status);
+}
 
 static double now_s(void)
 {
@@ -154,11 +180,15 @@ int run_tally(const pssbam_config *cfg, Genome *genome, const char *aln_path, in
     res->n_gpus = n_gpus;
     rc = 0;
 done:
-    for (int g = 0; g < n_gpus; g++)
-        if (eng[g]) pssbam_engine_destroy(eng[g]);
-    if (registered) pssbam_host_unregister(buf_base);
-    bam_reader_close(rd);
-    sam_reader_close(sd);
+    t_mark = now_s();
+    if (!(frontend_fast_exit && rc == 0)) {
+        for (int g = 0; g < n_gpus; g++)
+            if (eng[g]) pssbam_engine_destroy(eng[g]);
+        if (registered) pssbam_host_unregister(buf_base);
+        bam_reader_close(rd);
+        sam_reader_close(sd);
+    }
+    if (verbose) fprintf(stderr, "[pssbam] teardown %.3f s\n", now_s() - t_mark);
     res->total_s = now_s() - t0;
     if (rc) run_result_free(res);
     return rc;

@@ -84,6 +84,7 @@ int main(int argc, char *argv[])
     fprintf(stderr, " -U %s -D %s%s\n", up_ctx, down_ctx, merged_only ? " -m" : "");
 
     fprintf(stderr, "Reading genome sequence from:\n%s\n", fasta_fn);
+    frontend_warmup_start();   /* HIP start-up overlaps the FASTA load */
     Genome *genome = init_genome(fasta_fn);
     if (!genome) {
         fprintf(stderr, "Error: Unable to load genome from %s.\n", fasta_fn);
@@ -107,6 +108,7 @@ int main(int argc, char *argv[])
     cfg.kernel = PSSBAM_KERNEL_AUTO;
 
     run_result res;
+    frontend_fast_exit = getenv("PSSBAM_CLEAN_EXIT") == NULL;
     if (run_tally(&cfg, genome, bam_fn, env_gpu_count(), &res)) exit(1);
 
     double *fwd_rates = (double *)calloc((size_t)(region_len ? region_len : 1) * 12, sizeof(double));
@@ -120,6 +122,10 @@ int main(int argc, char *argv[])
         static const char *nm[] = {"records", "rg_dropped", "parse_skip", "no_contig", "pss_ok", "pss_filtered"};
         for (int i = 0; i < 6; i++) fprintf(stderr, "[pssbam] %s=%llu\n", nm[i], (unsigned long long)res.stats[i]);
         fprintf(stderr, "[pssbam] gpus=%d inflate_s=%.3f total_s=%.3f\n", res.n_gpus, res.inflate_s, res.total_s);
+    }
+    if (frontend_fast_exit) { /* nothing left to do but to hand the memory back: let the OS */
+        fprintf(stderr, "Done.\n");
+        front_end_exit(0);
     }
     free(fwd_rates);
     free(rev_rates);

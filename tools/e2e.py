@@ -53,6 +53,7 @@ m = re.search(r"gpus=(\d+) inflate_s=([\d.]+) total_s=([\d.]+)", pr.stderr)
 inflate_s, tally_s = float(m.group(2)), float(m.group(3))
 phases = re.search(r"phases: (.*) s\n", pr.stderr)
 reader = re.search(r"reader thread: (.*) s\n", pr.stderr)
+teardown = re.search(r"teardown ([\d.]+) s", pr.stderr)
 rec_bytes = sum(int(x) for x in synth.sizes_host(cfg, 0, 1000, threads=1)) / 1000 * args.reads
 print(json.dumps({
     "reads": args.reads, "bam_bytes": bam.stat().st_size, "inflated_record_bytes": rec_bytes, "fasta_bytes": fa.stat().st_size,
@@ -62,7 +63,7 @@ print(json.dumps({
     "reads_per_s_tally_phase": args.reads / tally_s, "reads_per_s_whole_command": args.reads / wall,
     "inflate_GBps": rec_bytes / inflate_s / 1e9 if inflate_s else None,
     "workload_gen_s": {"fasta": t_fa, "bam": t_bam}, "phases": phases.group(1) if phases else None,
-    "reader_thread": reader.group(1) if reader else None,
+    "reader_thread": reader.group(1) if reader else None, "teardown_s": float(teardown.group(1)) if teardown else None,
 }))
 for p in tmp.iterdir():
     p.unlink()
