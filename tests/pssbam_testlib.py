@@ -597,7 +597,9 @@ def ref_safe(recs: list[Rec], klen: int | None = None) -> list[Rec]:
 
 
 def random_pss_opts(rng: np.random.Generator) -> PssOpts:
-    ctx_choices = ["ACGT", "ACGT", "ACGT", "CT", "G", "ACGTN", "TA"]
+    # sets with non-ACGT members (and different ones per side) exercise the "other base" classes of
+    # the packed reference; lower case can never match (the genome is upper-cased at load)
+    ctx_choices = ["ACGT", "ACGT", "ACGT", "CT", "G", "ACGTN", "TA", "N", "NR", "ACGTNRY", "acgt", "GY"]
     lo = int(rng.choice([0, 0, 10, 25]))
     hi = int(rng.choice([250000000, 250000000, 60, 120]))
     return PssOpts(region_len=int(rng.choice([1, 5, 8, 15, 25, 30, 31, 40])), min_read_len=lo,
