@@ -763,22 +763,16 @@ bool load_rccl() {
 }
 }  // namespace
 
-extern "C" int pssbam_reduce_counters(pssbam_engine *const *engines, int n, int root) {
-    if (!engines || n < 1 || root < 0 || root >= n) return fail(PSSBAM_EINVAL, "bad argument");
-    for (int i = 0; i < n; i++) {
-        if (!engines[i]) return fail(PSSBAM_EINVAL, "null engine %d", i);
-        if (engines[i]->n_counters != engines[0]->n_counters)
-            return fail(PSSBAM_EINVAL, "engines were created with different options");
-        int rc = pssbam_engine_sync(engines[i]);
-        if (rc) return rc;
-    }
-    if (n == 1) return PSSBAM_OK;
-    if (!load_rccl()) return fail(PSSBAM_EHIP, "librccl.so could not be loaded: %s", dlerror());
+// One grouped ncclReduce over the engines' counter blocks (single process, one communicator per
+// GPU).  PSSBAM_OK = done; 1 = RCCL is not usable here and nothing was touched (the caller sums on
+// the host instead); negative = a collective failed half-way, the counters are not trustworthy.
+static int reduce_rccl(pssbam_engine *const *engines, int n, int root) {
+    if (!load_rccl()) return 1;
     std::vector<ncclComm_t> comms(n);
     std::vector<int> devs(n);
     for (int i = 0; i < n; i++) devs[i] = engines[i]->device;
     int rc = g_rccl.CommInitAll(comms.data(), n, devs.data());
-    if (rc != 0) return fail(PSSBAM_EHIP, "ncclCommInitAll failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
+    if (rc != 0) return 1;
     rc = g_rccl.GroupStart();
     for (int i = 0; i < n && rc == 0; i++) {
         (void)hipSetDevice(engines[i]->device);
@@ -793,6 +787,40 @@ extern "C" int pssbam_reduce_counters(pssbam_engine *const *engines, int n, int 
     }
     for (int i = 0; i < n; i++) (void)g_rccl.CommDestroy(comms[i]);
     if (rc != 0) return fail(PSSBAM_EHIP, "ncclReduce failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
+    return PSSBAM_OK;
+}
+
+extern "C" int pssbam_reduce_counters(pssbam_engine *const *engines, int n, int root) {
+    if (!engines || n < 1 || root < 0 || root >= n) return fail(PSSBAM_EINVAL, "bad argument");
+    for (int i = 0; i < n; i++) {
+        if (!engines[i]) return fail(PSSBAM_EINVAL, "null engine %d", i);
+        if (engines[i]->n_counters != engines[0]->n_counters)
+            return fail(PSSBAM_EINVAL, "engines were created with different options");
+        int rc = pssbam_engine_sync(engines[i]);
+        if (rc) return rc;
+    }
+    if (n == 1) return PSSBAM_OK;
+    // RCCL needs one distinct device per rank; anything else (two engines on one GPU, librccl
+    // missing, a failing communicator) takes the host-side sum below, which is also the
+    // cross-check path (PSSBAM_REDUCE=host)
+    bool distinct = true;
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < i; j++) distinct = distinct && engines[i]->device != engines[j]->device;
+    const char *force = getenv("PSSBAM_REDUCE");
+    if (distinct && !(force && !strcmp(force, "host"))) {
+        const int rc = reduce_rccl(engines, n, root);
+        if (rc <= 0) return rc;
+    }
+
+    const size_t nc = engines[0]->n_counters;
+    std::vector<unsigned long long> sum(nc, 0ull), part(nc);
+    for (int i = 0; i < n; i++) {
+        HIP_TRY(hipSetDevice(engines[i]->device));
+        HIP_TRY(hipMemcpy(part.data(), engines[i]->d_counters, nc * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        for (size_t k = 0; k < nc; k++) sum[k] += part[k];
+    }
+    HIP_TRY(hipSetDevice(engines[root]->device));
+    HIP_TRY(hipMemcpy(engines[root]->d_counters, sum.data(), nc * sizeof(unsigned long long), hipMemcpyHostToDevice));
     return PSSBAM_OK;
 }
 

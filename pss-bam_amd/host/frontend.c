@@ -55,6 +55,9 @@ int env_gpu_count(void)
     int want = v ? atoi(v) : 1, have = pssbam_device_count();
     if (want < 1) want = 1;
     if (have < 1) have = 1; /* engine creation reports the real problem */
+    /* PSSBAM_OVERSUBSCRIBE: several engines per device (engine g on device g % devices) -- lets
+     * the multi-engine path (batch dealing, counter sum) be exercised on a one-GPU machine */
+    if (getenv("PSSBAM_OVERSUBSCRIBE")) return want > 64 ? 64 : want;
     return want > have ? have : want;
 }
 
@@ -99,7 +102,8 @@ int run_tally(const pssbam_config *cfg, Genome *genome, const char *aln_path, in
     t_open = now_s() - t_mark; t_mark = now_s();
     for (int g = 0; g < n_gpus; g++) {
         pssbam_config c = *cfg;
-        c.device = g;
+        const int have = pssbam_device_count();
+        c.device = have > 0 ? g % have : g;
         if (pssbam_engine_create(&c, &eng[g]) || pssbam_engine_set_genome(eng[g], genome)) {
             fprintf(stderr, "Error: GPU engine %d: %s\n", g, pssbam_last_error());
             goto done;

@@ -102,6 +102,19 @@ def test_cli_on_generated_bam_vs_oracle(bins, oracle, tmp_path):
     assert pr.returncode == 0, pr.stderr
     g5, g3 = tl.parse_fragkon_text(pr.stdout)
     assert np.array_equal(g5, w5) and np.array_equal(g3, w3)
+    # the multi-engine path of the front ends (PSSBAM_NGPU: batches dealt round-robin to one engine
+    # per GPU, counter blocks summed at the end), run here with three engines sharing the one GPU
+    # and small batches so that every engine gets several; same tables, both ways of summing
+    for reduce in ("", "host"):
+        env = {**os.environ, "PSSBAM_NGPU": "3", "PSSBAM_OVERSUBSCRIBE": "1", "PSSBAM_BATCH_BYTES": str(1 << 20),
+               "PSSBAM_REDUCE": reduce, "PSSBAM_STATS": "1"}
+        pr = subprocess.run([str(bins / "pss-bam"), "-F", str(fa), "-B", str(bam), "-o", str(tmp_path / "out3")] + po.argv(),
+                            capture_output=True, text=True, env=env)
+        assert pr.returncode == 0, pr.stderr
+        assert "gpus=3" in pr.stderr
+        gf, gr = tl.parse_counts_text((tmp_path / "out3.pss.counts.txt").read_text())
+        assert np.array_equal(gf, wf) and np.array_equal(gr, wr)
+        assert f"records={n}" in pr.stderr
 
 
 def test_reduce_counters_single_engine_is_identity(tmp_path):
