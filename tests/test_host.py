@@ -500,3 +500,70 @@ def test_sam_reader_encodes_what_line2saml_accepts(host, tmp_path):
     assert f[0] == "noncanon" and f[5] == "*"
     f = lines[-1].rstrip("\n").split("\t")
     assert f[0] == "lower" and f[2] == "chrNew" and f[4] == "255" and f[9] == "ACN" and f[11:] == ["RG:Z:g9"]
+
+
+def _sam_reader_all(L, path, batch):
+    """all encoded record bytes + the reference names the reader ends with + skipped count"""
+    L.sam_reader_open.restype = C.c_void_p
+    L.sam_reader_open.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
+    L.sam_reader_next.restype = C.c_int64
+    L.sam_reader_next.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    L.sam_reader_n_ref.argtypes = [C.c_void_p]
+    L.sam_reader_ref_names.restype = C.POINTER(C.c_char_p)
+    L.sam_reader_ref_names.argtypes = [C.c_void_p]
+    L.sam_reader_lines_skipped.restype = C.c_uint64
+    L.sam_reader_lines_skipped.argtypes = [C.c_void_p]
+    L.sam_reader_close.argtypes = [C.c_void_p]
+    err = C.create_string_buffer(256)
+    rd = L.sam_reader_open(str(path).encode(), batch, err, 256)
+    assert rd, err.value
+    chunks, n_rec, n_batches = [], 0, 0
+    while True:
+        recs_p, offs_p, nb = C.c_void_p(), C.c_void_p(), C.c_size_t()
+        n = L.sam_reader_next(rd, C.byref(recs_p), C.byref(offs_p), C.byref(nb))
+        assert n >= 0
+        if n == 0:
+            break
+        offs = np.ctypeslib.as_array(C.cast(offs_p, C.POINTER(C.c_uint32)), shape=(n + 1,))
+        assert offs[0] == 0 and offs[n] == nb.value and np.all(np.diff(offs.astype(np.int64)) >= 36)
+        chunks.append(C.string_at(recs_p.value, nb.value))
+        n_rec += n
+        n_batches += 1
+    names = [L.sam_reader_ref_names(rd)[i].decode() for i in range(L.sam_reader_n_ref(rd))]
+    skipped = L.sam_reader_lines_skipped(rd)
+    L.sam_reader_close(rd)
+    return b"".join(chunks), n_rec, names, skipped, n_batches
+
+
+def test_sam_reader_threads_and_batch_seams(host, tmp_path):
+    """the multi-threaded text parser gives byte-identical records, names and counts whatever the
+    thread count and batch size (pieces and batches are cut at line starts), from plain and gzip
+    text, with RNAMEs the header never announced and a line longer than fgets' MAX_LINE_LEN"""
+    import gzip
+    L, _ = host
+    _, refs, recs = tl.fuzz_dataset(91, 30000, with_rg=True)
+    sam = tmp_path / "big.sam"
+    tl.write_sam(sam, refs, recs)
+    with open(sam, "a") as fh:
+        fh.write("late1\t0\tchrLateA\t5\t30\t3M\t*\t0\t0\tACG\tIII\n")
+        fh.write("x" * 450000 + "\t0\tchrA\t5\t30\t3M\t*\t0\t0\tACG\tIII\n")   # cut into 200000-char "lines": all rejected
+        fh.write("late2\t16\tchrLateB\t9\t30\t2M\t*\t0\t0\tAC\tII\n")
+        fh.write("late3\t0\tchrLateA\t6\t30\t3M\t*\t0\t0\tACG\tIII")              # no final newline
+    gz = tmp_path / "big.sam.gz"
+    gz.write_bytes(gzip.compress(sam.read_bytes(), 1))
+    assert sam.stat().st_size > (4 << 20)
+    want = None
+    for threads, batch, path in (("1", 0, sam), ("7", 1 << 20, sam), ("16", 3 << 20, sam), ("5", 1 << 20, gz), ("1", 0, gz)):
+        os.environ["PSSBAM_SAM_THREADS"] = threads
+        try:
+            got = _sam_reader_all(L, path, batch)
+        finally:
+            del os.environ["PSSBAM_SAM_THREADS"]
+        if want is None:
+            want = got
+            assert got[1] == sum(1 for r in recs if len(r.seq) == len(r.qual)) + 3
+            assert got[2][-2:] == ["chrLateA", "chrLateB"] and got[3] >= 3
+        else:
+            assert got[:4] == want[:4], (threads, batch, path.name)
+        if batch:
+            assert got[4] > 3   # really several batches
