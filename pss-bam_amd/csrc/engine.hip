@@ -664,10 +664,29 @@ extern "C" int pssbam_engine_genome_kmer_count(pssbam_engine *e, int klen, uint6
     unsigned long long *d_bins = nullptr;
     HIP_TRY(hipMalloc(&d_bins, nb * sizeof(unsigned long long)));
     HIP_TRY(hipMemsetAsync(d_bins, 0, nb * sizeof(unsigned long long), e->stream));
-    const uint32_t blocks = (uint32_t)std::min<uint64_t>((e->genome_bytes / GKC_SPAN + 255) / 256 + 1, (uint64_t)e->n_cu * 16);
-    if (klen <= 6) hipLaunchKernelGGL(genome_kmer_kernel<true>, dim3(blocks), dim3(256), 0, e->stream, e->d_genome, e->genome_bytes, klen, d_bins);
-    else hipLaunchKernelGGL(genome_kmer_kernel<false>, dim3(blocks), dim3(256), 0, e->stream, e->d_genome, e->genome_bytes, klen, d_bins);
-    hipError_t le = hipGetLastError();
+    hipError_t le = hipSuccess;
+    if (klen <= 8 && e->d_genome4 && !getenv("PSSBAM_GKC_BYTES")) {
+        // histogram in LDS from the packed genome; replication of the bins while they are few
+        const uint32_t n_all = 1u << (2 * klen);
+        const uint32_t n_bins = std::min<uint32_t>(n_all, 32768u);                 // per pass: <= 128 KiB of u32
+        uint32_t rep_log2 = 0;
+        while ((n_bins << (rep_log2 + 1)) * 4u <= 32768u && rep_log2 < 5) rep_log2++;  // up to 32 KiB of replicas
+        const uint32_t lds = (n_bins << rep_log2) * 4u;
+        le = hipFuncSetAttribute((const void *)genome_kmer_packed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const uint64_t spans = (e->genome_bytes + GKC4_SPAN - 1) / GKC4_SPAN;
+        const uint32_t per_cu = lds > 65536u ? 1u : 2u;
+        const uint32_t blocks = (uint32_t)std::min<uint64_t>((spans + 511) / 512, (uint64_t)e->n_cu * per_cu);
+        for (uint32_t lo = 0; lo < n_all && le == hipSuccess; lo += n_bins) {
+            hipLaunchKernelGGL(genome_kmer_packed_kernel, dim3(blocks), dim3(512), lds, e->stream, e->d_genome4, e->genome_bytes, klen,
+                               lo, n_bins, rep_log2, d_bins);
+            le = hipGetLastError();
+        }
+    } else {
+        const uint32_t blocks = (uint32_t)std::min<uint64_t>((e->genome_bytes / GKC_SPAN + 255) / 256 + 1, (uint64_t)e->n_cu * 16);
+        if (klen <= 6) hipLaunchKernelGGL(genome_kmer_kernel<true>, dim3(blocks), dim3(256), 0, e->stream, e->d_genome, e->genome_bytes, klen, d_bins);
+        else hipLaunchKernelGGL(genome_kmer_kernel<false>, dim3(blocks), dim3(256), 0, e->stream, e->d_genome, e->genome_bytes, klen, d_bins);
+        le = hipGetLastError();
+    }
     if (le == hipSuccess) le = hipMemcpyAsync(counts, d_bins, nb * sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream);
     if (le == hipSuccess) le = hipStreamSynchronize(e->stream);
     (void)hipFree(d_bins);

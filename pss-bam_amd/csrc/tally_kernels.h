@@ -673,6 +673,67 @@ __global__ void __launch_bounds__(256) genome_kmer_kernel(const uint8_t *genome,
     }
 }
 
+// The same census for k <= 8 from the 4-bit packed genome, with the whole histogram (or half of
+// it per pass at k = 8) in LDS:
+//   - a lane walks GKC4_SPAN consecutive positions = 128 packed bytes with a rolling 2-bit code,
+//     eight dwordx4 loads per span;
+//   - bins are REPLICATED rep times (lane & (rep-1) picks the copy, copies of a bin sit in adjacent
+//     words = different banks): the AAAA / TTTT / poly-N skew of a real genome would otherwise
+//     serialise the lanes of a wave on a few words;
+//   - bin_lo / n_bins select the slice of the 4^k bins this pass owns (k = 8: two passes of 32 Ki
+//     bins = 128 KiB of LDS each); one u64 global atomic per non-empty bin per workgroup at the end.
+constexpr uint32_t GKC4_SPAN = 256;
+__global__ void __launch_bounds__(512) genome_kmer_packed_kernel(const uint32_t *g4, uint64_t n_pos, int K, uint32_t bin_lo,
+                                                                 uint32_t n_bins, uint32_t rep_log2,
+                                                                 unsigned long long *bins) {
+    extern __shared__ uint32_t lds_hist[];
+    const uint32_t rep = 1u << rep_log2;
+    for (uint32_t i = threadIdx.x; i < (n_bins << rep_log2); i += blockDim.x) lds_hist[i] = 0u;
+    __syncthreads();
+    const uint32_t mask = (1u << (2 * K)) - 1u;
+    const uint32_t copy = threadIdx.x & (rep - 1u);
+    const uint64_t n_spans = (n_pos + GKC4_SPAN - 1) / GKC4_SPAN;
+    for (uint64_t sp = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; sp < n_spans; sp += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t p0 = sp * GKC4_SPAN;
+        const uint4 *src = (const uint4 *)(g4 + p0 / 8);
+        uint32_t code = 0u, run = 0u;
+        if (p0) {  // warm-up: the K-1 <= 7 positions before the span are in the previous dword
+            const uint32_t w = g4[p0 / 8 - 1];
+#pragma unroll
+            for (int b = 1; b < 8; b++) {
+                const uint32_t c = (w >> (4 * b)) & 15u;
+                run = c < 4u ? run + 1u : 0u;
+                code = (code << 2) | (c & 3u);
+            }
+            run = min(run, (uint32_t)(K - 1));  // windows starting before the span belong to the previous one
+        }
+#pragma unroll 2
+        for (int q = 0; q < (int)(GKC4_SPAN / 32); q++) {
+            if (p0 + 32ull * q >= n_pos) break;
+            const uint4 v = src[q];
+            const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+#pragma unroll
+                for (int b = 0; b < 8; b++) {
+                    const uint32_t c = (w4[d] >> (4 * b)) & 15u;
+                    run = c < 4u ? run + 1u : 0u;
+                    code = ((code << 2) | (c & 3u)) & mask;
+                    const uint32_t slot = code - bin_lo;
+                    if (run >= (uint32_t)K && slot < n_bins && p0 + 32ull * q + 8u * d + b < n_pos)
+                        atomicAdd(&lds_hist[(slot << rep_log2) + copy], 1u);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n_bins; i += blockDim.x) {
+        uint32_t sum = 0u;
+        for (uint32_t r = 0; r < rep; r++) sum += lds_hist[(i << rep_log2) + r];
+        if (sum) atomicAdd(&bins[bin_lo + i], (unsigned long long)sum);
+    }
+}
+
 // Upload-time genome transform: toupper() fold (init_genome stores upper case,
 // fasta-genome-io.c:127; process_aln folds again, pss-bam.c:424) followed by the
 // A/C/G/T <-> 0..3 byte swap of record_decode.h.  16 bytes per lane per step.

@@ -176,8 +176,14 @@ def test_genome_kmer_count_engine_vs_oracle(oracle, tmp_path):
     g = oracle.load_genome(fa)
     eng = pkg.Engine(kmer=dict(klen=4))
     eng.set_genome_arrays(tl.loaded_contigs(contigs))
-    for k in (1, 2, 4, 6, 7, 10, 12):
+    for k in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12):   # <= 8: packed genome + LDS histogram (two passes at 8); above: global bins
         want = oracle.genome_kmer_count(g, k)
         assert np.array_equal(eng.genome_kmer_count(k), want.astype(np.uint64)), k
+    os.environ["PSSBAM_GKC_BYTES"] = "1"            # the byte-genome kernel stays as the cross-check
+    try:
+        for k in (4, 8):
+            assert np.array_equal(eng.genome_kmer_count(k), oracle.genome_kmer_count(g, k).astype(np.uint64)), k
+    finally:
+        del os.environ["PSSBAM_GKC_BYTES"]
     eng.close()
     oracle.free_genome(g)
