@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <memory>
 #include <vector>
 
 #include "tally_kernels.h"
@@ -167,6 +168,8 @@ extern "C" int pssbam_engine_create(const pssbam_config *cfg, pssbam_engine **ou
     HIP_TRY(hipSetDevice(dev));
 
     pssbam_engine *e = new pssbam_engine();
+    // a failure below releases what was set up so far (destroy tolerates a half-built engine)
+    std::unique_ptr<pssbam_engine, void (*)(pssbam_engine *)> guard(e, pssbam_engine_destroy);
     e->cfg = *cfg;
     e->device = dev;
     if (cfg->tally_mask & PSSBAM_TALLY_PSS) {
@@ -210,7 +213,7 @@ extern "C" int pssbam_engine_create(const pssbam_config *cfg, pssbam_engine **ou
     e->env_simple_blocks = env_int("PSSBAM_SIMPLE_BLOCKS");
     e->env_grid_wgs = env_int("PSSBAM_GRID_WGS");
     e->env_pieces = env_int("PSSBAM_PIECES");
-    *out = e;
+    *out = guard.release();
     return PSSBAM_OK;
 }
 

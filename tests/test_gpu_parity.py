@@ -212,3 +212,51 @@ def test_large_region_len_uses_generic_kernel(pkg, oracle, tmp_path):
             _check_pss(got, wf, wr, st)
     finally:
         oracle.free_genome(g)
+
+
+def test_c_abi_error_conventions(pkg, tmp_path):
+    """0 = ok, negative PSSBAM_E* + a message from pssbam_last_error(); the library never exits
+    (INTEGRATION.md): wrong call order, bad options, malformed blocks"""
+    contigs, refs, recs = tl.fuzz_dataset(5, 50)
+    raw = np.frombuffer(tl.raw_records(refs, recs), dtype=np.uint8)
+    with pytest.raises(pkg.PssbamError, match="tally_mask"):
+        pkg.Engine()                                              # neither tally requested
+    with pytest.raises(pkg.PssbamError, match="klen"):
+        pkg.Engine(kmer=dict(klen=13))
+    with pytest.raises(pkg.PssbamError, match="region_len"):
+        pkg.Engine(pss=dict(region_len=-1))
+    with pytest.raises(pkg.PssbamError, match="does not exist"):
+        pkg.Engine(pss=dict(region_len=5), device=99)
+    with pytest.raises(pkg.PssbamError, match="tiled kernel supports"):
+        e = pkg.Engine(pss=dict(region_len=31), kernel=pkg.KERNEL_TILED)
+        e.set_genome_arrays(tl.loaded_contigs(contigs))
+        e.set_references([r[0] for r in refs])
+        try:
+            e.submit(raw)
+        finally:
+            e.close()
+    eng = pkg.Engine(pss=dict(region_len=5))
+    try:
+        with pytest.raises(pkg.PssbamError, match="set_genome"):
+            eng.submit(raw)                                       # no genome yet
+        with pytest.raises(pkg.PssbamError, match="set_genome must precede"):
+            eng.set_references([r[0] for r in refs])
+        eng.set_genome_arrays(tl.loaded_contigs(contigs))
+        with pytest.raises(pkg.PssbamError, match="set_references"):
+            eng.submit(raw)                                       # no reference table yet
+        eng.set_references([r[0] for r in refs])
+        offs = pkg.index_records(raw)
+        bad = offs.copy()
+        bad[-1] -= 1
+        with pytest.raises(pkg.PssbamError, match="offsets"):
+            eng.submit(raw, bad)                                  # index does not cover the block
+        with pytest.raises(pkg.PssbamError, match="partial record"):
+            eng.submit(raw[:-3])                                  # the Python wrapper's own framing check
+        torn = raw.copy()
+        torn[0:4] = np.frombuffer(np.uint32(7).tobytes(), dtype=np.uint8)   # block_size < 32
+        with pytest.raises(pkg.PssbamError, match="block_size"):
+            pkg.index_records(torn)
+        eng.submit(raw, offs)                                     # and the engine is still usable
+        assert eng.finish().stats["records"] == len(recs)
+    finally:
+        eng.close()
