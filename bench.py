@@ -66,6 +66,7 @@ def main():
     ap.add_argument("--unsorted", action="store_true", help="shuffled record order (gather stress)")
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 simple, 2 tiled")
     ap.add_argument("--cpu-sample", type=int, default=2_000_000, help="reads timed on the host reference")
+    ap.add_argument("--region-len", type=int, default=None, help="override the configuration's -r N (parity cases / large-N passes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-cores", type=int, default=1,
                     help="> 1: also time one reference process per core on disjoint shards (SURVEY 8d's all-cores figure)")
@@ -102,6 +103,8 @@ def main():
 
     cd = synth.config(args.config, sorted_=not args.unsorted, scale_genome=args.scale_genome)
     region_len = cd.pop("region_len")
+    if args.region_len is not None:
+        region_len = args.region_len
     klen = cd.pop("klen", None)
     per_gpu = args.reads if args.reads is not None else cd["n_reads"]
     cd["n_reads"], slot0, _ = shard_of(rank, world, per_gpu)

@@ -48,8 +48,9 @@ extern "C" {
 
 /* kernel selection (diagnostics / tests; 0 lets the engine choose) */
 #define PSSBAM_KERNEL_AUTO 0
-#define PSSBAM_KERNEL_SIMPLE 1  /* lane-per-read, global gathers (any N, any k)          */
-#define PSSBAM_KERNEL_TILED 2   /* LDS-staged record prefixes, lane=row tally (N <= 30)  */
+#define PSSBAM_KERNEL_SIMPLE 1  /* lane-per-read, global gathers: the cross-check kernel  */
+#define PSSBAM_KERNEL_TILED 2   /* LDS-staged record prefixes, lane=row tally; 32 table   */
+                                /* rows per pass over the block (what AUTO picks)         */
 
 /* pss-bam's option globals, /root/reference/pss-bam.c:12-18 (set by -r -l -L -q -U -D -m) */
 typedef struct pssbam_pss_opts {

@@ -2,8 +2,9 @@
 //
 //  tally_simple : lane-per-read, records and reference bases gathered straight from
 //                 global memory, counts into an LDS table (or global atomics when the
-//                 table would not fit).  Any -r N, any k.  Fallback + cross-check.
-//  tally_tiled  : the production kernel for N <= 30.  Persistent workgroups walk tiles
+//                 table would not fit).  Any -r N, any k.  Cross-check of tally_tiled.
+//  tally_tiled  : the production kernel.  One launch tallies 32 table rows (N <= 30: all of
+//                 them; a larger -r takes one launch per 32 rows).  Persistent workgroups walk tiles
 //                 of T = 128 consecutive reads:
 //                   1. STAGE   LDS-DMA (global_load_lds_dwordx4) with a PER-LANE source address:
 //                              lane q of the tile's piece list fetches 16-byte piece q % P of
@@ -44,7 +45,8 @@ namespace pssbam {
 
 constexpr int TILED_THREADS = 256;
 constexpr int TILED_WAVES = TILED_THREADS / 64;
-constexpr int TILED_MAX_N = 30;        // N+2 positions per end must fit 32 lanes
+constexpr int TILED_ROWS = 32;         // table rows (window positions per end) one pass covers; a larger
+                                       // N+2 takes several passes over the block, 32 rows each (row_base)
 constexpr int KMER_LDS_MAX_K = 4;      // 2 * 4^4 * 4 B = 2 KiB of LDS
 constexpr uint32_t STAGE_SLACK = 64;   // readable bytes behind a staging buffer
 constexpr uint32_t CODE_NONE = 32;     // sheet byte meaning "no count"; every code >= 32 is one
@@ -63,10 +65,12 @@ struct LdsTableRowMajor {  // [table][row][16] u32 in LDS
         atomicAdd(&t[(table * rows + row) * 16u + cell], 1u);
     }
 };
-struct LdsTableColumnMajor {  // [(cell << 1) | table][32 rows] u32 in LDS (tiled kernel)
+struct LdsTableColumnMajor {  // [(cell << 1) | table][32 rows] u32 in LDS (tiled kernel): rows row_base .. +31
     uint32_t *t;
+    uint32_t row_base;
     __device__ __forceinline__ void add(uint32_t table, uint32_t row, uint32_t cell) const {
-        atomicAdd(&t[(((cell << 1) | table) << 5) + row], 1u);
+        const uint32_t r = row - row_base;
+        if (r < 32u) atomicAdd(&t[(((cell << 1) | table) << 5) + r], 1u);
     }
 };
 struct GlobalTable {  // straight into the u64 counter block
@@ -246,7 +250,7 @@ __device__ __attribute__((noinline)) uint32_t tally_overflow_record(const TallyP
     GlobalBytes gsrc{P.recs + o0};
     const RecHdr gh = decode_hdr(gsrc, o1 - o0);
     const Plan gpl = make_plan<DO_PSS, DO_KMER>(P, gsrc, gh);
-    if (DO_PSS && (gpl.pss_fwd || gpl.pss_rev)) tally_pss_record(P, LdsTableColumnMajor{table}, gsrc, gh, gpl);
+    if (DO_PSS && (gpl.pss_fwd || gpl.pss_rev)) tally_pss_record(P, LdsTableColumnMajor{table, P.row_base}, gsrc, gh, gpl);
     bool kfail = false;
     if (DO_KMER && (gpl.fk5 || gpl.fk3)) kfail = tally_kmer_record<LDS_KMER>(P, gpl, lds_kmer);
     return record_events(DO_PSS, DO_KMER, gpl, kfail);
@@ -277,6 +281,11 @@ __device__ __forceinline__ void tally_tiled_body(const TallyParams &P, const Tal
     const uint32_t lane = tid & 63u, wave = tid >> 6;
     const int N = P.N;
     const uint32_t n_pos = (uint32_t)N + 2u;  // rows per table: 2 context + N positions
+    // this launch tallies rows row_base .. row_base+31 (window positions shifted accordingly);
+    // pass 0 also owns the status counters and the k-mer tally
+    const uint32_t row_base = P.row_base;
+    const bool pass0 = row_base == 0u;
+    const uint32_t n_live = n_pos > row_base ? min(n_pos - row_base, 32u) : 0u;
 
     // ---- one-time set-up: zero the tables ---------------------------------------------------------
     for (uint32_t i = tid; i < TABLE_WORDS; i += TILED_THREADS) table[i] = 0u;
@@ -352,7 +361,7 @@ __device__ __forceinline__ void tally_tiled_body(const TallyParams &P, const Tal
         uint32_t gq[5] = {0u, 0u, 0u, 0u, 0u};
         uint32_t gsh = 0u;
         if (cand) {
-            const uint64_t ga = pl.gbase + (uint64_t)pl.s + (e ? (uint64_t)pl.L - 30ull : (uint64_t)-2ll);
+            const uint64_t ga = pl.gbase + (uint64_t)pl.s + (e ? (uint64_t)pl.L - 30ull - row_base : (uint64_t)row_base - 2ull);
             const uint32_t *pg = P.genome4 + (ga >> 3);
             if (!(ablate & 128u)) {
                 const Quad q0 = *(const Quad *)pg;
@@ -362,16 +371,24 @@ __device__ __forceinline__ void tally_tiled_body(const TallyParams &P, const Tal
             }
             gsh = 4u * (uint32_t)(ga & 7ull);
         }
+        // the first context base of this end (position s-1 / s+L) decides -U / -D in every pass; only
+        // the window of pass 0 holds it
+        uint32_t cx = 0u;
+        if (cand && !pass0) {
+            const uint64_t pc = pl.gbase + (uint64_t)pl.s + (e ? (uint64_t)pl.L : (uint64_t)-1ll);
+            cx = (P.genome4[pc >> 3] >> (4u * (uint32_t)(pc & 7ull))) & 15u;
+        }
         // read bases of this end as a nibble stream aligned with the window bytes: stream nibble
         // b <-> read base n0 + b, n0 = -2 (left: bytes 0,1 are context, their nibbles are never
         // used) or L-30 (right).  20 bytes from SEQ as six aligned dwords, one batch.
-        const int32_t n0 = e ? (int32_t)pl.L - 30 : -2;
+        const int32_t n0 = e ? (int32_t)pl.L - 30 - (int32_t)row_base : (int32_t)row_base - 2;
         uint32_t rr[6];
 #pragma unroll
         for (int k = 0; k < 6; k++) rr[k] = 0u;
         uint32_t ssh = 0u;
         if (cand) {
-            const uint32_t sa = src.off + (uint32_t)((int32_t)h.seq_off + (n0 >> 1));  // arithmetic shift = floor
+            const int32_t n0a = min(n0, (int32_t)h.l_seq);  // (past SEQ everything is blanked anyway: stay inside the record)
+            const uint32_t sa = src.off + (uint32_t)((int32_t)h.seq_off + (n0a >> 1));  // arithmetic shift = floor
             const uint32_t *qs = (const uint32_t *)(stage + (sa & ~3u));
             ssh = sa & 3u;
 #pragma unroll
@@ -396,7 +413,7 @@ __device__ __forceinline__ void tally_tiled_body(const TallyParams &P, const Tal
         uint32_t ev_over = 0u;  // events of a record handled by the out-of-line path
         if (in_tile && !in_stage && e == 0u) {
             ev_over = tally_overflow_record<DO_PSS, DO_KMER, LDS_KMER>(kernarg, o0, o1, table, lds_kmer);
-            atomicAdd(&lds_delta[ST_SLOW_PATH], 1);
+            if (pass0) atomicAdd(&lds_delta[ST_SLOW_PATH], 1);
         }
         // First use of the gathered registers happens HERE, before the next tile's DMA is issued:
         // vmcnt retires in order and hipcc's counted wait for these loads cannot see the
@@ -410,6 +427,7 @@ __device__ __forceinline__ void tally_tiled_body(const TallyParams &P, const Tal
         // pin those uses here (the scheduler would otherwise sink them below the DMA issue)
 #pragma unroll
         for (int m = 0; m < 4; m++) asm volatile("" : "+v"(W[m]));
+        asm volatile("" : "+v"(cx));
         if (DO_KMER) {
 #pragma unroll
             for (int k = 0; k < 2; k++) asm volatile("" : "+v"(kw[k]));
@@ -427,7 +445,7 @@ __device__ __forceinline__ void tally_tiled_body(const TallyParams &P, const Tal
         // ---- CODES, part B: registers only ------------------------------------------------------------
         {
             // first context base next to the alignment: left window position 1 (s-1), right position 30 (s+L)
-            const uint32_t own1 = e ? (W[3] >> 24) & 15u : (W[0] >> 4) & 15u;
+            const uint32_t own1 = !pass0 ? cx : e ? (W[3] >> 24) & 15u : (W[0] >> 4) & 15u;
             const uint32_t other1 = (uint32_t)__shfl_xor((int)own1, 1);
             if (DO_PSS) plan_finish_pss_packed(P.acgt_ctx, pl, e ? other1 : own1, e ? own1 : other1);
             uint32_t code_w[8];
@@ -478,7 +496,7 @@ __device__ __forceinline__ void tally_tiled_body(const TallyParams &P, const Tal
                 // shorter than the window), so the whole wave skips it when no lane needs it.
                 const int32_t have_s = (int32_t)h.l_seq - n0;
                 const uint32_t have = have_s <= 0 ? 0u : have_s >= 32 ? 32u : (uint32_t)have_s;
-                if (__any(have < (e ? 30u : 32u))) {
+                if (__any(have < (e && pass0 ? 30u : 32u))) {
 #pragma unroll
                     for (int m = 0; m < 4; m++) {
                         // bytes i of E[m] with 8m + 2i < have, of O[m] with 8m + 2i + 1 < have
@@ -492,7 +510,7 @@ __device__ __forceinline__ void tally_tiled_body(const TallyParams &P, const Tal
                 // reference base (pss-bam.c:172-184).  Left: positions 0,1 = byte 0 of E[0], O[0];
                 // right: positions 30,31 = byte 3 of E[3], O[3].
                 {
-                    const uint32_t ml = e ? 0u : 0x000000FFu, mr = e ? 0xFF000000u : 0u;
+                    const uint32_t ml = (e || !pass0) ? 0u : 0x000000FFu, mr = (e && pass0) ? 0xFF000000u : 0u;
                     RE[0] = (RE[0] & ~ml) | ((GE[0] << 2) & ml & 0x18181818u);
                     RO[0] = (RO[0] & ~ml) | ((GO[0] << 2) & ml & 0x18181818u);
                     RE[3] = (RE[3] & ~mr) | ((GE[3] << 2) & mr & 0x18181818u);
@@ -535,7 +553,7 @@ __device__ __forceinline__ void tally_tiled_body(const TallyParams &P, const Tal
                 const int bad_other = __shfl_xor(bad, 1);  // every lane takes part in the exchange
                 kfail = (bad | bad_other) != 0;
             }
-            if (e == 0u) book_events(DO_PSS, DO_KMER, in_stage ? record_events(DO_PSS, DO_KMER, pl, kfail) : ev_over, lds_delta);
+            if (e == 0u && pass0) book_events(DO_PSS, DO_KMER, in_stage ? record_events(DO_PSS, DO_KMER, pl, kfail) : ev_over, lds_delta);
         }
         __syncthreads();
 
@@ -547,7 +565,7 @@ __device__ __forceinline__ void tally_tiled_body(const TallyParams &P, const Tal
             const uint32_t row = e ? 31u - wpos : wpos;
             const uint32_t per_wave = (count + TILED_WAVES - 1u) / TILED_WAVES;
             const uint32_t j0 = wave * per_wave, j1 = min(count, j0 + per_wave);
-            if (row < n_pos) {  // (lanes of dead rows would only ever see CODE_NONE)
+            if (row < n_live) {  // (lanes of dead rows would only ever see CODE_NONE)
                 uint32_t j = j0;
                 for (; j + 8u <= j1; j += 8u) {
                     uint32_t c[8];
@@ -586,14 +604,14 @@ __global__ void __launch_bounds__(256) reduce_partials(const TallyParams P, uint
     unsigned long long *dst = nullptr;
     bool is_delta = false;
     if (i < 1024u) {
-        const uint32_t row = i & 31u, ct = i >> 5, t = ct & 1u, cell = ct >> 1;
+        const uint32_t row = P.row_base + (i & 31u), ct = i >> 5, t = ct & 1u, cell = ct >> 1;
         if (do_pss && row < n_pos) dst = &P.counters[(t ? P.off_rev : 0u) + row * 16u + cell];
     } else if (i < SCRATCH_DELTA) {
         const uint32_t k = i - SCRATCH_KMER, nb = do_kmer ? 1u << (2 * P.K) : 0u;
         if (lds_kmer_on && k < 2u * nb) dst = &P.counters[k < nb ? P.off_k5 + k : P.off_k3 + (k - nb)];
     } else {
-        const uint32_t k = i - SCRATCH_DELTA;
-        if (k < (uint32_t)ST_USED) { dst = &P.counters[P.off_stats + k]; is_delta = true; }
+        const uint32_t k = i - SCRATCH_DELTA;  // status counters belong to pass 0
+        if (k < (uint32_t)ST_USED && P.row_base == 0u) { dst = &P.counters[P.off_stats + k]; is_delta = true; }
     }
     if (!dst) return;
     long long sum = 0;

@@ -602,7 +602,7 @@ def random_pss_opts(rng: np.random.Generator) -> PssOpts:
     ctx_choices = ["ACGT", "ACGT", "ACGT", "CT", "G", "ACGTN", "TA", "N", "NR", "ACGTNRY", "acgt", "GY"]
     lo = int(rng.choice([0, 0, 10, 25]))
     hi = int(rng.choice([250000000, 250000000, 60, 120]))
-    return PssOpts(region_len=int(rng.choice([1, 5, 8, 15, 25, 30, 31, 40])), min_read_len=lo,
+    return PssOpts(region_len=int(rng.choice([1, 5, 8, 15, 25, 30, 31, 40, 70])), min_read_len=lo,
                    max_read_len=hi, min_mq=int(rng.choice([0, 0, 20, 37])),
                    up_ctx=str(rng.choice(ctx_choices)), down_ctx=str(rng.choice(ctx_choices)),
                    merged_only=bool(rng.random() < 0.3))

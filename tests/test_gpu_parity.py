@@ -77,7 +77,7 @@ def test_fuzz_both_kernels_match_oracle(pkg, oracle, tmp_path, seed):
             ko = tl.FkOpts(klen=4) if trial == 0 else tl.random_fk_opts(rng)
             wf, wr, st = oracle.pss(g, sam, po)
             w5, w3, stk = oracle.fragkon(g, sam, ko)
-            kernels = [pkg.KERNEL_SIMPLE] + ([pkg.KERNEL_TILED] if po.region_len <= 30 else [])
+            kernels = [pkg.KERNEL_SIMPLE, pkg.KERNEL_TILED]   # the tiled kernel takes a large -r in passes of 32 rows
             for kern in kernels:
                 got = _engine_tables(pkg, contigs, refs, raw, pss=_pss_dict(po), kmer=_fk_dict(ko), kernel=kern,
                                      chunks=1 + trial)
@@ -102,7 +102,7 @@ def test_golden_pss_from_bam(pkg, case):
     fa_txt = (GOLD / ds["fasta"]).read_text()
     contigs = [(blk.split("\n", 1)[0].split()[0], "".join(blk.split("\n")[1:])) for blk in fa_txt.split(">")[1:]]
     wf, wr = tl.parse_counts_text((GOLD / case["counts"]).read_text())
-    for kern in (pkg.KERNEL_SIMPLE, pkg.KERNEL_TILED) if o.region_len <= 30 else (pkg.KERNEL_SIMPLE,):
+    for kern in (pkg.KERNEL_SIMPLE, pkg.KERNEL_TILED):
         got = _engine_tables(pkg, contigs, refs, raw, pss=_pss_dict(o), rg=o.read_group, kernel=kern)
         assert np.array_equal(got.fwd, wf) and np.array_equal(got.rev, wr)
 
@@ -197,7 +197,9 @@ def test_tile_overflow_path(pkg, oracle, tmp_path, monkeypatch):
     assert np.array_equal(got.k5, w5.astype(np.uint64)) and np.array_equal(got.k3, w3.astype(np.uint64))
 
 
-def test_large_region_len_uses_generic_kernel(pkg, oracle, tmp_path):
+def test_large_region_len(pkg, oracle, tmp_path):
+    """-r beyond one 32-row pass: the tiled kernel (AUTO's choice for every N) walks the block once
+    per 32 table rows"""
     contigs, refs, recs = tl.fuzz_dataset(88, 1500)
     fa, sam = tmp_path / "g.fa", tmp_path / "a.sam"
     tl.write_fasta(fa, contigs)
@@ -205,11 +207,13 @@ def test_large_region_len_uses_generic_kernel(pkg, oracle, tmp_path):
     g = oracle.load_genome(fa)
     raw = tl.raw_records(refs, recs)
     try:
-        for n in (31, 64, 200, 1100):
+        for n in (31, 62, 63, 64, 100, 200, 254, 255, 1100):
             po = tl.PssOpts(region_len=n)
             wf, wr, st = oracle.pss(g, sam, po)
-            got = _engine_tables(pkg, contigs, refs, raw, pss=_pss_dict(po))     # AUTO
-            _check_pss(got, wf, wr, st)
+            for kern in (pkg.KERNEL_AUTO, pkg.KERNEL_SIMPLE):
+                got = _engine_tables(pkg, contigs, refs, raw, pss=_pss_dict(po), kmer=dict(klen=5), kernel=kern, chunks=3)
+                _check_pss(got, wf, wr, st)
+                assert got.stats["records"] == len(recs)
     finally:
         oracle.free_genome(g)
 
@@ -227,14 +231,6 @@ def test_c_abi_error_conventions(pkg, tmp_path):
         pkg.Engine(pss=dict(region_len=-1))
     with pytest.raises(pkg.PssbamError, match="does not exist"):
         pkg.Engine(pss=dict(region_len=5), device=99)
-    with pytest.raises(pkg.PssbamError, match="tiled kernel supports"):
-        e = pkg.Engine(pss=dict(region_len=31), kernel=pkg.KERNEL_TILED)
-        e.set_genome_arrays(tl.loaded_contigs(contigs))
-        e.set_references([r[0] for r in refs])
-        try:
-            e.submit(raw)
-        finally:
-            e.close()
     eng = pkg.Engine(pss=dict(region_len=5))
     try:
         with pytest.raises(pkg.PssbamError, match="set_genome"):
