@@ -219,7 +219,12 @@ int synth_fasta_host(const synth_cfg *c, const char *path, uint32_t first, uint3
 // A complete BGZF-compressed BAM file holding slots [slot0, slot0+n) (header with the contig
 // list, then the records), deflated by `threads` workers.  level 0..9 (1 = fast).  This is the
 // on-disk form the front ends consume; used by the end-to-end measurements and CLI tests.
-int synth_bam_file_host(const synth_cfg *c, uint64_t slot0, uint64_t n, const char *path, int level, int threads) {
+// layout 0: BGZF blocks the way htslib writes them -- the header in its own block(s), then whole
+// records per block (a block is closed when the next record would not fit 0xff00 bytes; bam_write1
+// calls bgzf_flush_try), so every block starts on a record boundary.  layout 1: the stream cut
+// every 0xff00 bytes regardless of records (what htsjdk-style writers produce).
+int synth_bam_file_host(const synth_cfg *c, uint64_t slot0, uint64_t n, const char *path, int level, int threads,
+                        int layout) {
     FILE *f = fopen(path, "wb");
     if (!f) return -1;
     // header bytes
@@ -247,6 +252,7 @@ int synth_bam_file_host(const synth_cfg *c, uint64_t slot0, uint64_t n, const ch
     const size_t BLK = 0xFF00;
     std::vector<uint8_t> raw, carry(head.begin(), head.end());
     std::vector<uint32_t> sizes, offs;
+    std::vector<size_t> cut;  // block boundaries within raw: block b = [cut[b], cut[b+1])
     int rc = 0;
     for (uint64_t a = 0; a < n || !carry.empty(); a += CHUNK_READS) {
         const uint64_t m = a < n ? std::min<uint64_t>(CHUNK_READS, n - a) : 0;
@@ -260,13 +266,31 @@ int synth_bam_file_host(const synth_cfg *c, uint64_t slot0, uint64_t n, const ch
         std::copy(carry.begin(), carry.end(), raw.begin());
         if (m) synth_records_host(c, slot0 + a, m, offs.data(), raw.data() + carry.size(), threads);
         const bool last = a + m >= n;
-        // whole BGZF blocks now, remainder carried (flushed on the last round)
-        const size_t n_blk = last ? (raw.size() + BLK - 1) / BLK : raw.size() / BLK;
+        cut.clear();
+        cut.push_back(0);
+        if (layout == 0) {
+            // carry = the BAM header (first round only; flushed as its own blocks), never records:
+            // in this layout every round ends on a record boundary
+            const size_t lead = carry.size();
+            for (size_t o = 0; o < lead;) { o = std::min(lead, o + BLK); cut.push_back(o); }
+            size_t blk_start = lead;
+            for (uint64_t i = 0; i < m; i++) {
+                const size_t r0 = lead + offs[i], r1 = lead + offs[i + 1];
+                if (r1 - blk_start > BLK && r0 > blk_start) { cut.push_back(r0); blk_start = r0; }  // flush before a record that does not fit
+                while (r1 - blk_start > BLK) { blk_start += BLK; cut.push_back(blk_start); }        // a record larger than a block is split
+            }
+            if (raw.size() > blk_start) cut.push_back(raw.size());
+        } else {
+            // whole 0xff00-byte blocks now, remainder carried (flushed on the last round)
+            const size_t n_whole = last ? (raw.size() + BLK - 1) / BLK : raw.size() / BLK;
+            for (size_t b = 1; b <= n_whole; b++) cut.push_back(std::min(raw.size(), b * BLK));
+        }
+        const size_t n_blk = cut.size() - 1;
         std::vector<std::vector<uint8_t>> out(n_blk);
         parallel_for(n_blk, threads, [&](uint64_t b0, uint64_t b1) {
             z_stream zs;
             for (uint64_t b = b0; b < b1; b++) {
-                const size_t o = b * BLK, len = std::min(BLK, raw.size() - o);
+                const size_t o = cut[b], len = cut[b + 1] - cut[b];
                 memset(&zs, 0, sizeof zs);
                 deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
                 std::vector<uint8_t> &dst = out[b];
@@ -289,7 +313,7 @@ int synth_bam_file_host(const synth_cfg *c, uint64_t slot0, uint64_t n, const ch
         });
         for (auto &d : out)
             if (fwrite(d.data(), 1, d.size(), f) != d.size()) rc = -1;
-        carry.assign(raw.begin() + std::min(raw.size(), n_blk * BLK), raw.end());
+        carry.assign(raw.begin() + cut.back(), raw.end());
         if (last) break;
     }
     static const uint8_t eof_blk[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};

@@ -11,10 +11,12 @@
  *      of the mapping are taken by the workers, in parallel.  The payload starts `gap` bytes
  *      into the slot: room for the partial record the previous batch ended with, which is
  *      not known yet.
- *   2. INDEX (indexer thread): put the carried partial record in front of the payload, follow
- *      the block_size chain to index whole records (a dependent-load chain, one cache miss per
- *      record: as expensive as the inflate of the batch on 32 threads, hence its own stage),
- *      keep the trailing partial record for the next batch.
+ *   2. INDEX (indexer thread): put the carried partial record in front of the payload and
+ *      follow the block_size chain to index whole records.  The inflate workers have already
+ *      walked every block from its first byte; wherever the chain arrives exactly at a block
+ *      start (always, in files written by htslib) the block's records are taken over as a
+ *      whole, elsewhere the chain is a dependent-load walk, one cache miss per record.  The
+ *      trailing partial record is kept for the next batch.
  *   3. bam_reader_next() hands an indexed slot over and gives the previous one back.
  * So the caller's work on batch i (H2D copy + kernel), the indexing of batch i+1 and the
  * inflate of batch i+2 overlap.
@@ -49,6 +51,10 @@ typedef struct {
     uint32_t xlen;
     uint32_t isize;
     size_t uoff;     /* destination offset in the batch slot        */
+    /* records found by walking the inflated block from its first byte, as if it started on a
+     * record boundary (htslib-written files: it does); their offsets are in slot_t.spec */
+    uint32_t spec_n;
+    uint32_t spec_end; /* where that walk stopped: isize, or the start of a record that runs on */
 } blk_t;
 
 #define N_SLOTS 3
@@ -63,6 +69,10 @@ typedef struct {
     size_t rec_end;    /* end of the last whole record                                    */
     uint32_t *offs;    /* n_recs + 1 offsets relative to `start`                          */
     size_t offs_cap, n_recs;
+    blk_t *blk;        /* the BGZF blocks inflated into this slot                         */
+    size_t n_blk, blk_cap;
+    uint32_t *spec;    /* speculative record offsets (from buf), block b's at spec[uoff/32 ..]:
+                          a record is > 32 bytes, so the regions of two blocks never overlap */
     int state;         /* guarded by bam_reader.mu                                        */
     int eof;           /* no records: the input is exhausted                              */
     int rc;            /* -1: the fill failed, bam_reader.err says why                    */
@@ -91,8 +101,6 @@ struct bam_reader {
     int hdr_parsed;    /* parse_header() got through */
     pthread_mutex_t mu;
     pthread_cond_t cv;
-    blk_t *blk;
-    size_t n_blk, blk_cap;
     bam_header hdr;
     char err[256];
     double inflate_s, scan_s, index_s, wait_s; /* producer's wall time per phase */
@@ -104,7 +112,7 @@ struct bam_reader {
     pthread_cond_t job_cv, done_cv;
     unsigned long job_gen;
     int job_active, job_quit;
-    uint8_t *job_dst;
+    slot_t *job_slot;  /* the slot the current inflate job fills */
     atomic_size_t job_next;
     atomic_int job_failed;
     pss_inflater *own_inf; /* the producer's own decoder state */
@@ -149,20 +157,34 @@ static long bgzf_block_len(const uint8_t *p, size_t avail, uint32_t *xlen_out)
 
 /* ---- inflate workers ------------------------------------------------------------------------ */
 
-/* inflates blocks of the current job until the shared counter runs past the table */
+/* inflates blocks of the current job until the shared counter runs past the table; every
+ * block is then walked for records from its first byte (see blk_t.spec_n) */
 static void inflate_blocks(bam_reader *r, pss_inflater *inf)
 {
+    slot_t *s = r->job_slot;
     for (;;) {
         const size_t i = atomic_fetch_add(&r->job_next, GRAB);
-        if (i >= r->n_blk) break;
-        for (size_t k = i; k < i + GRAB && k < r->n_blk; k++) {
-            const blk_t *b = &r->blk[k];
+        if (i >= s->n_blk) break;
+        for (size_t k = i; k < i + GRAB && k < s->n_blk; k++) {
+            blk_t *b = &s->blk[k];
             const uint8_t *src = r->cdata + b->coff;
-            uint8_t *dst = r->job_dst + b->uoff;
+            uint8_t *dst = s->buf + b->uoff;
+            b->spec_n = b->spec_end = 0;
             if (b->isize == 0) continue;
             if (pss_inflate_raw(inf, src + 12 + b->xlen, b->clen - 12 - b->xlen - 8, dst, b->isize) != 0 ||
-                pss_crc32(0, dst, b->isize) != le32(src + b->clen - 8))
+                pss_crc32(0, dst, b->isize) != le32(src + b->clen - 8)) {
                 atomic_store(&r->job_failed, 1);
+                continue;
+            }
+            uint32_t *out = s->spec + b->uoff / 32, n = 0, o = 0;
+            while (o + 4 <= b->isize) {
+                const uint32_t bs = le32(dst + o);
+                if (bs < 32 || bs > b->isize - o - 4) break; /* not a record start, or it runs on */
+                out[n++] = (uint32_t)b->uoff + o;
+                o += 4 + bs;
+            }
+            b->spec_n = n;
+            b->spec_end = o;
         }
     }
 }
@@ -188,11 +210,11 @@ static void *worker_main(void *arg)
     return NULL;
 }
 
-/* inflates r->blk[0 .. n_blk) into dst; 0 ok / -1 error */
-static int run_inflate(bam_reader *r, uint8_t *dst)
+/* inflates s->blk[0 .. n_blk) into the slot; 0 ok / -1 error */
+static int run_inflate(bam_reader *r, slot_t *s)
 {
     const double t0 = now_s();
-    r->job_dst = dst;
+    r->job_slot = s;
     atomic_store(&r->job_next, 0);
     atomic_store(&r->job_failed, 0);
     if (r->n_workers > 0) {
@@ -217,13 +239,15 @@ static int run_inflate(bam_reader *r, uint8_t *dst)
 
 /* ---- producer ------------------------------------------------------------------------------- */
 
-/* Inflates as many whole BGZF blocks as fit into dst[first .. first + ucap); *len_out = end of
- * the payload, *full = stopped because the next block does not fit (not because the input ended). */
-static int fill_buffer(bam_reader *r, uint8_t *dst, size_t first, size_t *len_out, int *full)
+/* Inflates as many whole BGZF blocks as fit into the slot's payload area [gap, gap + ucap);
+ * s->len = end of the payload, s->full = stopped because the next block does not fit (not
+ * because the input ended). */
+static int fill_slot(bam_reader *r, slot_t *s)
 {
     const double t0 = now_s();
-    r->n_blk = 0;
-    *full = 0;
+    const size_t first = r->gap;
+    s->n_blk = 0;
+    s->full = 0;
     size_t uoff = first;
     while (r->cpos < r->clen) {
         uint32_t xlen = 0;
@@ -234,21 +258,21 @@ static int fill_buffer(bam_reader *r, uint8_t *dst, size_t first, size_t *len_ou
         if ((size_t)bl < 12u + xlen + 8u) { set_err(r, "BGZF block shorter than its own header"); return -1; }
         const uint32_t isize = le32(r->cdata + r->cpos + bl - 4);
         if (isize > BGZF_MAX_BLOCK) { set_err(r, "BGZF ISIZE %u exceeds 64 KiB", isize); return -1; }
-        if (uoff + isize > first + r->ucap) { *full = 1; break; }
-        if (r->n_blk == r->blk_cap) {
-            const size_t cap = r->blk_cap ? r->blk_cap * 2 : 8192;
-            blk_t *nb = (blk_t *)realloc(r->blk, cap * sizeof(blk_t));
+        if (uoff + isize > first + r->ucap) { s->full = 1; break; }
+        if (s->n_blk == s->blk_cap) {
+            const size_t cap = s->blk_cap ? s->blk_cap * 2 : 8192;
+            blk_t *nb = (blk_t *)realloc(s->blk, cap * sizeof(blk_t));
             if (!nb) { set_err(r, "out of memory"); return -1; }
-            r->blk = nb;
-            r->blk_cap = cap;
+            s->blk = nb;
+            s->blk_cap = cap;
         }
-        r->blk[r->n_blk++] = (blk_t){r->cpos, (uint32_t)bl, xlen, isize, uoff};
+        s->blk[s->n_blk++] = (blk_t){r->cpos, (uint32_t)bl, xlen, isize, uoff, 0, 0};
         uoff += isize;
         r->cpos += (size_t)bl;
     }
-    *len_out = uoff;
+    s->len = uoff;
     r->scan_s += now_s() - t0;
-    return r->n_blk ? run_inflate(r, dst) : 0;
+    return s->n_blk ? run_inflate(r, s) : 0;
 }
 
 /* BAM header at p[0 .. len); 0 ok (*end_out = first record byte) / -1 error */
@@ -288,36 +312,67 @@ static int parse_header(bam_reader *r, const uint8_t *p, size_t len, int input_d
     return 0;
 }
 
-/* indexes the whole records of s->buf[s->start .. len); 0 ok / -1 error */
-static int index_slot(bam_reader *r, slot_t *s, size_t len)
+static int offs_reserve(bam_reader *r, slot_t *s, size_t need)
 {
-    size_t o = s->start, n = 0, stride = 0;
-    while (o + 4 <= len) {
-        const uint32_t bs = le32(s->buf + o);
-        if (bs < 32) { set_err(r, "alignment record with block_size %u < 32", bs); return -1; }
-        if (o + 4 + (size_t)bs > len) break;
-        /* The walk is a chain of dependent loads, one cache miss per record.  Records of one
-         * file are of similar size, so the length word PREFETCH_AHEAD records further on is
-         * close to o + AHEAD * (mean record size so far): touching that line and its neighbours
-         * turns most of the misses into hits (a wrong guess costs nothing but the prefetch). */
-        if ((n & 63u) == 0) stride = n ? (o - s->start) / n : 4 + (size_t)bs;
-        {
-            const uint8_t *guess = s->buf + o + PREFETCH_AHEAD * stride;
-            if (guess + 128 < s->buf + len) {
-                __builtin_prefetch(guess - 64, 0, 0);
-                __builtin_prefetch(guess, 0, 0);
-                __builtin_prefetch(guess + 64, 0, 0);
+    if (need <= s->offs_cap) return 0;
+    size_t cap = s->offs_cap ? s->offs_cap : ((size_t)1 << 20);
+    while (cap < need) cap *= 2;
+    uint32_t *no = (uint32_t *)realloc(s->offs, cap * sizeof(uint32_t));
+    if (!no) { set_err(r, "out of memory"); return -1; }
+    s->offs = no;
+    s->offs_cap = cap;
+    return 0;
+}
+
+/* Indexes the whole records of s->buf[s->start .. s->len); 0 ok / -1 error.
+ * The record chain is followed block by block.  Whenever it arrives exactly at the first byte of
+ * a BGZF block, that block's records were already found by the inflate worker (blk_t.spec_n) and
+ * are taken over wholesale -- in a file written by htslib every block starts on a record
+ * boundary, so the serial part shrinks to one step per block.  Anywhere else (the carried
+ * partial record, a record that runs over a block seam, files whose blocks are cut regardless of
+ * records) the chain is walked record by record: a dependent-load chain, one cache miss each,
+ * softened by prefetching where the next length words are expected. */
+static int index_slot(bam_reader *r, slot_t *s)
+{
+    const size_t len = s->len;
+    size_t o = s->start, n = 0, stride = 0, walked = 0, walk_from = o;
+    size_t b = 0; /* first block that may still contain o */
+    int stop = 0;
+    while (!stop && o + 4 <= len) {
+        while (b < s->n_blk && s->blk[b].uoff + s->blk[b].isize <= o) b++;
+        if (b < s->n_blk && s->blk[b].uoff == o && s->blk[b].spec_n) {
+            const blk_t *k = &s->blk[b];
+            if (offs_reserve(r, s, n + k->spec_n + 2)) return -1;
+            const uint32_t *src = s->spec + k->uoff / 32;
+            const uint32_t base = (uint32_t)s->start;
+            for (uint32_t i = 0; i < k->spec_n; i++) s->offs[n + i] = src[i] - base;
+            n += k->spec_n;
+            o = k->uoff + k->spec_end;
+            walk_from = o;
+            walked = 0;
+            continue;
+        }
+        /* serial steps up to the end of the current block (or of the carry in front of block 0) */
+        const size_t seam = b < s->n_blk ? (o < s->blk[b].uoff ? s->blk[b].uoff : s->blk[b].uoff + s->blk[b].isize) : len;
+        while (o < seam) {
+            if (o + 4 > len) { stop = 1; break; }
+            const uint32_t bs = le32(s->buf + o);
+            if (bs < 32) { set_err(r, "alignment record with block_size %u < 32", bs); return -1; }
+            if (o + 4 + (size_t)bs > len) { stop = 1; break; }
+            if ((walked & 63u) == 0) stride = walked ? (o - walk_from) / walked : 4 + (size_t)bs;
+            {
+                const uint8_t *guess = s->buf + o + PREFETCH_AHEAD * stride;
+                if (guess + 128 < s->buf + len) {
+                    __builtin_prefetch(guess - 64, 0, 0);
+                    __builtin_prefetch(guess, 0, 0);
+                    __builtin_prefetch(guess + 64, 0, 0);
+                }
             }
+            if (offs_reserve(r, s, n + 2)) return -1;
+            s->offs[n++] = (uint32_t)(o - s->start);
+            o += 4 + (size_t)bs;
+            walked++;
         }
-        if (n + 2 > s->offs_cap) {
-            const size_t cap = s->offs_cap ? s->offs_cap * 2 : (1u << 20);
-            uint32_t *no = (uint32_t *)realloc(s->offs, cap * sizeof(uint32_t));
-            if (!no) { set_err(r, "out of memory"); return -1; }
-            s->offs = no;
-            s->offs_cap = cap;
-        }
-        s->offs[n++] = (uint32_t)(o - s->start);
-        o += 4 + (size_t)bs;
     }
     if (n) s->offs[n] = (uint32_t)(o - s->start);
     s->n_recs = n;
@@ -353,7 +408,7 @@ static void *producer_main(void *arg)
         if (slot_await(r, s, SLOT_FREE)) break;
         r->wait_s += now_s() - tw;
         s->len = r->gap;
-        s->rc = fill_buffer(r, s->buf, r->gap, &s->len, &s->full);
+        s->rc = fill_slot(r, s);
         const int last = s->rc != 0 || s->len == r->gap; /* error, or nothing left to inflate */
         slot_publish(r, s, SLOT_FILLED);
         if (last) break;
@@ -386,7 +441,7 @@ static void *indexer_main(void *arg)
                 s->start += hdr_end;
             }
         }
-        if (rc == 0) rc = index_slot(r, s, s->len);
+        if (rc == 0) rc = index_slot(r, s);
         if (rc == 0 && s->n_recs == 0 && s->len > s->start) {
             /* bytes in hand but not one whole record */
             if (s->full) {
@@ -501,7 +556,11 @@ bam_reader *bam_reader_open(const char *path, int n_threads, size_t batch_bytes,
         set_err(r, "out of memory");
         goto fail;
     }
-    for (int w = 0; w < N_SLOTS; w++) r->slot[w].buf = r->ubase + (size_t)w * slot_bytes;
+    for (int w = 0; w < N_SLOTS; w++) {
+        r->slot[w].buf = r->ubase + (size_t)w * slot_bytes;
+        r->slot[w].spec = (uint32_t *)malloc(((r->gap + r->ucap) / 32 + 64) * sizeof(uint32_t));
+        if (!r->slot[w].spec) { set_err(r, "out of memory"); goto fail; }
+    }
 
     r->own_inf = (pss_inflater *)malloc(sizeof(pss_inflater));
     /* the producer counts as one inflater */
@@ -584,9 +643,12 @@ void bam_reader_close(bam_reader *r)
     else free((void *)r->cdata);
     if (r->fd >= 0) close(r->fd);
     free(r->ubase);
-    free(r->blk);
     free(r->own_inf);
-    for (int w = 0; w < N_SLOTS; w++) free(r->slot[w].offs);
+    for (int w = 0; w < N_SLOTS; w++) {
+        free(r->slot[w].offs);
+        free(r->slot[w].blk);
+        free(r->slot[w].spec);
+    }
     free(r->carry);
     free(r->hdr.text);
     if (r->hdr.ref_name)

@@ -46,7 +46,7 @@ def lib() -> C.CDLL:
         L.synth_offsets_linear_device.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]
         L.synth_sam_host.argtypes = [P, C.c_uint64, C.c_uint64, C.c_char_p, C.c_int]
         L.synth_fasta_host.argtypes = [P, C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]
-        L.synth_bam_file_host.argtypes = [P, C.c_uint64, C.c_uint64, C.c_char_p, C.c_int, C.c_int]
+        L.synth_bam_file_host.argtypes = [P, C.c_uint64, C.c_uint64, C.c_char_p, C.c_int, C.c_int, C.c_int]
         _lib = L
     return _lib
 
@@ -135,7 +135,8 @@ def fasta_host(cfg: SynthCfg, path, first: int = 0, count: int | None = None, wi
         raise OSError(f"cannot write {path}")
 
 
-def bam_file_host(cfg: SynthCfg, slot0: int, n: int, path, level: int = 1, threads: int = 8) -> None:
-    """BGZF-compressed BAM file (header + records of slots [slot0, slot0+n))"""
-    if lib().synth_bam_file_host(C.byref(cfg), slot0, n, str(path).encode(), level, threads) != 0:
+def bam_file_host(cfg: SynthCfg, slot0: int, n: int, path, level: int = 1, threads: int = 8, ragged: bool = False) -> None:
+    """BGZF-compressed BAM file (header + records of slots [slot0, slot0+n)).  Default block layout is
+    htslib's (whole records per block); ragged=True cuts the stream every 0xff00 bytes instead."""
+    if lib().synth_bam_file_host(C.byref(cfg), slot0, n, str(path).encode(), level, threads, int(ragged)) != 0:
         raise OSError(f"cannot write {path}")

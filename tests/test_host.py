@@ -567,3 +567,29 @@ def test_sam_reader_threads_and_batch_seams(host, tmp_path):
             assert got[:4] == want[:4], (threads, batch, path.name)
         if batch:
             assert got[4] > 3   # really several batches
+
+
+def test_bam_reader_block_layouts(host, tmp_path):
+    """the same records in htslib's block layout (every BGZF block starts on a record boundary: the
+    reader takes the inflate workers' per-block record lists) and cut every 0xff00 bytes regardless
+    of records (serial chain walk), small and default batches: identical text, equal to the
+    model's independently written SAM twin"""
+    _, pkg = host
+    from pss_bam_amd import synth
+    exe = pkg.PKG_DIR / "bin" / "bam2sam"
+    d = synth.config("C4", n_reads=150_000, scale_genome=0.0005)
+    d.pop("region_len")
+    cfg = synth.make_cfg(**d)
+    n = int(cfg.n_reads)
+    sam = tmp_path / "twin.sam"
+    synth.sam_host(cfg, 0, n, sam, with_header=False)
+    want = sam.read_text()
+    for ragged in (False, True):
+        bam = tmp_path / f"layout{int(ragged)}.bam"
+        synth.bam_file_host(cfg, 0, n, bam, level=1, threads=4, ragged=ragged)
+        for batch in ("0", "262144", "1048576"):
+            env = dict(os.environ)
+            if batch != "0":
+                env["PSSBAM_BATCH_BYTES"] = batch
+            got = subprocess.run([str(exe), str(bam)], capture_output=True, text=True, check=True, env=env).stdout
+            assert got == want, (ragged, batch)

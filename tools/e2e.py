@@ -23,6 +23,7 @@ ap.add_argument("--reads", type=int, default=10_000_000)
 ap.add_argument("--scale-genome", type=float, default=0.1)
 ap.add_argument("--level", type=int, default=1)
 ap.add_argument("--config", default="C2")
+ap.add_argument("--ragged", action="store_true", help="BGZF blocks cut every 0xff00 bytes regardless of records (default: htslib's layout)")
 args = ap.parse_args()
 
 pkg = ge.load_pkg()
@@ -39,7 +40,7 @@ t = time.time()
 synth.fasta_host(cfg, fa, threads=threads)
 t_fa = time.time() - t
 t = time.time()
-synth.bam_file_host(cfg, 0, args.reads, bam, level=args.level, threads=threads)
+synth.bam_file_host(cfg, 0, args.reads, bam, level=args.level, threads=threads, ragged=args.ragged)
 t_bam = time.time() - t
 env = {**os.environ, "PSSBAM_STATS": "1"}
 t = time.time()
@@ -57,7 +58,7 @@ teardown = re.search(r"teardown ([\d.]+) s", pr.stderr)
 rec_bytes = sum(int(x) for x in synth.sizes_host(cfg, 0, 1000, threads=1)) / 1000 * args.reads
 print(json.dumps({
     "reads": args.reads, "bam_bytes": bam.stat().st_size, "inflated_record_bytes": rec_bytes, "fasta_bytes": fa.stat().st_size,
-    "deflate_level": args.level, "host_threads": threads,
+    "deflate_level": args.level, "block_layout": "ragged" if args.ragged else "htslib", "host_threads": threads,
     "wall_s_whole_command": wall, "tally_phase_s": tally_s, "inflate_s": inflate_s,
     "genome_load_and_upload_s": wall - tally_s,
     "reads_per_s_tally_phase": args.reads / tally_s, "reads_per_s_whole_command": args.reads / wall,
