@@ -92,8 +92,9 @@ struct bam_reader {
     int take;          /* slot the next bam_reader_next() returns   */
     int held;          /* slot the caller is working on, or -1      */
     /* producer */
-    pthread_t producer, indexer;
-    int producer_started, indexer_started;
+    pthread_t producer, indexer, prefault;
+    int producer_started, indexer_started, prefault_started;
+    atomic_size_t scan_pos; /* how far the producer's block walk has got in the mapped input */
     uint8_t *carry;    /* indexer's copy of the partial record a batch ended with */
     size_t carry_len, carry_cap;
     int stop;          /* guarded by mu */
@@ -270,6 +271,7 @@ static int fill_slot(bam_reader *r, slot_t *s)
         uoff += isize;
         r->cpos += (size_t)bl;
     }
+    atomic_store(&r->scan_pos, r->cpos);
     s->len = uoff;
     r->scan_s += now_s() - t0;
     return s->n_blk ? run_inflate(r, s) : 0;
@@ -396,6 +398,31 @@ static int slot_await(bam_reader *r, slot_t *s, int state)
     const int stop = r->stop;
     pthread_mutex_unlock(&r->mu);
     return stop;
+}
+
+#ifndef MADV_POPULATE_READ
+#define MADV_POPULATE_READ 22 /* Linux 5.14+ */
+#endif
+/* Maps the input's page-cache pages a window ahead of the block walk, so that the walk (18 header
+ * bytes + 4 trailer bytes per block) and the inflate workers do not take the page faults one by
+ * one.  Purely an optimisation: without kernel support the call fails and the thread ends. */
+static void *prefault_main(void *arg)
+{
+    bam_reader *r = (bam_reader *)arg;
+    const size_t window = (size_t)192 << 20, step = (size_t)16 << 20;
+    size_t done = 0;
+    while (done < r->clen) {
+        pthread_mutex_lock(&r->mu);
+        const int stop = r->stop;
+        pthread_mutex_unlock(&r->mu);
+        if (stop) break;
+        const size_t want = atomic_load(&r->scan_pos) + window;
+        if (done >= want) { usleep(200); continue; }
+        const size_t n = r->clen - done < step ? r->clen - done : step;
+        if (madvise((void *)(r->cdata + done), n, MADV_POPULATE_READ) != 0) break;
+        done += n;
+    }
+    return NULL;
 }
 
 /* stage 1: inflate the next run of BGZF blocks into each free slot */
@@ -568,6 +595,7 @@ bam_reader *bam_reader_open(const char *path, int n_threads, size_t batch_bytes,
         if (pthread_create(&r->worker[r->n_workers], NULL, worker_main, r) != 0) break;
         r->n_workers++;
     }
+    if (r->mapped && pthread_create(&r->prefault, NULL, prefault_main, r) == 0) r->prefault_started = 1;
     if (pthread_create(&r->producer, NULL, producer_main, r) != 0) { set_err(r, "cannot start the reader thread"); goto fail; }
     r->producer_started = 1;
     if (pthread_create(&r->indexer, NULL, indexer_main, r) != 0) { set_err(r, "cannot start the indexer thread"); goto fail; }
@@ -632,6 +660,7 @@ void bam_reader_close(bam_reader *r)
     pthread_mutex_unlock(&r->mu);
     if (r->producer_started) pthread_join(r->producer, NULL);
     if (r->indexer_started) pthread_join(r->indexer, NULL);
+    if (r->prefault_started) pthread_join(r->prefault, NULL);
     if (r->n_workers) {
         pthread_mutex_lock(&r->job_mu);
         r->job_quit = 1;
