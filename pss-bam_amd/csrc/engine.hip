@@ -117,8 +117,8 @@ struct pssbam_engine {
     // tuning overrides (environment, for experiments)
     int env_tile_reads = 0, env_grid_mult = 0, env_simple_blocks = 0, env_grid_wgs = 0, env_pieces = 0;
     bool warned_ablate = false;
-    uint32_t prep_lds[8] = {0};     // prep_kernel's memo, by kernel variant
-    int prep_occ[8] = {0};
+    uint32_t prep_lds[16] = {0};    // prep_kernel's memo, by kernel variant
+    int prep_occ[16] = {0};
     uint32_t *d_scratch = nullptr;  // per-workgroup partial tables of the tiled kernel
     size_t scratch_slots = 0;
     uint32_t dev_pieces = 0;       // prefix pieces sampled from a device-resident block
@@ -530,9 +530,9 @@ static int launch_tally(pssbam_engine *e, const uint8_t *d_recs, uint64_t nbytes
         const uint32_t lds = tiled_lds_bytes(T, pieces);
         int occ = 0, rc = PSSBAM_OK;
         const int mult = e->env_grid_mult > 0 ? e->env_grid_mult : 1;
-#define LAUNCH_TILED(PSS, KM, LK)                                                                  \
+#define LAUNCH_TILED(PSS, KM, LK, LATER)                                                                  \
     do {                                                                                           \
-        rc = prep_kernel(e, (PSS ? 4 : 0) | (KM ? 2 : 0) | (LK ? 1 : 0), tally_tiled<PSS, KM, LK>, lds, &occ); \
+        rc = prep_kernel(e, (LATER ? 8 : 0) | (PSS ? 4 : 0) | (KM ? 2 : 0) | (LK ? 1 : 0), tally_tiled<PSS, KM, LK, LATER>, lds, &occ); \
         if (rc == PSSBAM_OK) {                                                                     \
             uint32_t grid = (uint32_t)std::min<uint64_t>(n_tiles, (uint64_t)e->n_cu * occ * mult); \
             if (e->env_grid_wgs > 0) grid = (uint32_t)std::min<uint64_t>(n_tiles, (uint64_t)e->env_grid_wgs); \
@@ -544,20 +544,20 @@ static int launch_tally(pssbam_engine *e, const uint8_t *d_recs, uint64_t nbytes
                 HIP_TRY(hipMalloc(&e->d_scratch, e->scratch_slots * SCRATCH_WORDS * sizeof(uint32_t))); \
             }                                                                                      \
             P.scratch = e->d_scratch;                                                              \
-            hipLaunchKernelGGL((tally_tiled<PSS, KM, LK>), dim3(grid), dim3(TILED_THREADS), lds, e->stream, P); \
+            hipLaunchKernelGGL((tally_tiled<PSS, KM, LK, LATER>), dim3(grid), dim3(TILED_THREADS), lds, e->stream, P); \
             hipLaunchKernelGGL(reduce_partials, dim3((SCRATCH_WORDS * REDUCE_GROUPS + 255) / 256), dim3(256), 0, e->stream, P, grid, \
                                (uint32_t)(LK ? 1 : 0));                                            \
         }                                                                                          \
     } while (0)
         P.row_base = 0;
-        if (do_pss && do_kmer) { if (kmer_lds) LAUNCH_TILED(true, true, true); else LAUNCH_TILED(true, true, false); }
-        else if (do_pss) LAUNCH_TILED(true, false, false);
-        else { if (kmer_lds) LAUNCH_TILED(false, true, true); else LAUNCH_TILED(false, true, false); }
+        if (do_pss && do_kmer) { if (kmer_lds) LAUNCH_TILED(true, true, true, false); else LAUNCH_TILED(true, true, false, false); }
+        else if (do_pss) LAUNCH_TILED(true, false, false, false);
+        else { if (kmer_lds) LAUNCH_TILED(false, true, true, false); else LAUNCH_TILED(false, true, false, false); }
         // rows 32.. of a large -r: further passes over the same block, substitution rows only
         // (the status counters and the k-mer tally belong to pass 0)
         for (uint32_t pass = 1; pass < n_passes && rc == PSSBAM_OK; pass++) {
             P.row_base = pass * TILED_ROWS;
-            LAUNCH_TILED(true, false, false);
+            LAUNCH_TILED(true, false, false, true);
         }
 #undef LAUNCH_TILED
         if (rc != PSSBAM_OK) return rc;

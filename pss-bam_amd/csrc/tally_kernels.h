@@ -189,7 +189,6 @@ __global__ void __launch_bounds__(256) tally_simple(const TallyParams P) {
 //   sheet  : TILED_MAX_T * 64                             code sheet [read][end*32 + position]
 //   table  : 64 * 32 * 4                                  [(cell<<1)|table][row] u32; codes 32..63 = trash bin
 //                                                         for "no count" codes, so the column pass has no branches
-//   ctxf   : 256                                          -U / -D membership flags per stored genome byte
 //   toffs  : 2 * (TILED_MAX_T + 4) * 4                    record offsets of this tile and the next
 //   kmer   : 2 * 4^KMER_LDS_MAX_K * 4                     (LDS_KMER variants only)
 //   refs   : (REF_LDS_ENTRIES + 1) * 16                   contig info of the first BAM references
@@ -265,11 +264,11 @@ __device__ __attribute__((noinline)) uint32_t tally_overflow_record(const TallyP
 // the count table and the offset buffer never alias the LDS-DMA destination (`stage`) -- without
 // it every LDS access issued while a DMA transfer is in flight is fenced behind vmcnt(0) and
 // the transfer cannot overlap the COLUMNS pass.
-template <bool DO_PSS, bool DO_KMER, bool LDS_KMER>
+template <bool DO_PSS, bool DO_KMER, bool LDS_KMER, bool LATER_PASS>
 __device__ __forceinline__ void tally_tiled_body(const TallyParams &P, const TallyParams *kernarg,
                                                  uint8_t *__restrict__ stage, uint8_t *__restrict__ sheet,
                                                  uint32_t *__restrict__ table,
-                                                 uint8_t *__restrict__ ctxf, uint32_t *__restrict__ toffs,
+                                                 uint32_t *__restrict__ toffs,
                                                  uint32_t *__restrict__ lds_kmer,
                                                  int32_t *__restrict__ lds_delta, uint4 *__restrict__ refs_lds) {
     const uint32_t T = P.reads_per_tile;   // <= TILED_MAX_T
@@ -283,8 +282,9 @@ __device__ __forceinline__ void tally_tiled_body(const TallyParams &P, const Tal
     const uint32_t n_pos = (uint32_t)N + 2u;  // rows per table: 2 context + N positions
     // this launch tallies rows row_base .. row_base+31 (window positions shifted accordingly);
     // pass 0 also owns the status counters and the k-mer tally
-    const uint32_t row_base = P.row_base;
-    const bool pass0 = row_base == 0u;
+    // (a compile-time 0 in the first-pass instantiation: the common N <= 30 case pays nothing)
+    const uint32_t row_base = LATER_PASS ? P.row_base : 0u;
+    const bool pass0 = !LATER_PASS;
     const uint32_t n_live = n_pos > row_base ? min(n_pos - row_base, 32u) : 0u;
 
     // ---- one-time set-up: zero the tables ---------------------------------------------------------
@@ -292,7 +292,6 @@ __device__ __forceinline__ void tally_tiled_body(const TallyParams &P, const Tal
     if (LDS_KMER)
         for (uint32_t i = tid; i < 2u * (1u << (2 * P.K)); i += TILED_THREADS) lds_kmer[i] = 0u;
     if (tid < ST_USED) lds_delta[tid] = 0;
-    if (tid < 256u) ctxf[tid] = (uint8_t)((in_set(P.up_mask, tid) ? 1u : 0u) | (in_set(P.down_mask, tid) ? 2u : 0u));
     // contig info of the first BAM references (all of them for a human-sized header) + the "*" entry
     const uint32_t n_ref_cached = min((uint32_t)P.n_ref, REF_LDS_ENTRIES);
     if (tid < n_ref_cached) refs_lds[tid] = P.ref_info[tid];
@@ -629,19 +628,18 @@ __global__ void __launch_bounds__(256) reduce_partials(const TallyParams P, uint
     if (sum) atomicAdd(dst, (unsigned long long)sum);
 }
 
-template <bool DO_PSS, bool DO_KMER, bool LDS_KMER>
+template <bool DO_PSS, bool DO_KMER, bool LDS_KMER, bool LATER_PASS = false>
 __global__ void __launch_bounds__(TILED_THREADS) tally_tiled(const TallyParams P) {
     extern __shared__ __attribute__((aligned(16))) uint8_t stage[];
     __shared__ __attribute__((aligned(16))) uint8_t sheet[TILED_MAX_T * 64u];
     __shared__ uint32_t table[TABLE_WORDS];
-    __shared__ uint8_t ctxf[256];
     __shared__ uint32_t toffs[2u * (TILED_MAX_T + 4u)];
     __shared__ uint32_t lds_kmer[LDS_KMER ? 2u * (1u << (2 * KMER_LDS_MAX_K)) : 1u];
     __shared__ int32_t lds_delta[ST_USED];
     __shared__ uint4 refs_lds[REF_LDS_ENTRIES + 1];
     // the kernel's single argument, as it lies in the kernarg segment (for the out-of-line path)
     const TallyParams *kernarg = (const TallyParams *)__builtin_amdgcn_kernarg_segment_ptr();
-    tally_tiled_body<DO_PSS, DO_KMER, LDS_KMER>(P, kernarg, stage, sheet, table, ctxf, toffs, lds_kmer, lds_delta, refs_lds);
+    tally_tiled_body<DO_PSS, DO_KMER, LDS_KMER, LATER_PASS>(P, kernarg, stage, sheet, table, toffs, lds_kmer, lds_delta, refs_lds);
 }
 
 // genome-kmer-count (genome-kmer-count.c:69-79): every k-mer start of the device genome.  Each
