@@ -51,8 +51,11 @@ typedef struct {
     uint32_t xlen;
     uint32_t isize;
     size_t uoff;     /* destination offset in the batch slot        */
-    /* records found by walking the inflated block from its first byte, as if it started on a
-     * record boundary (htslib-written files: it does); their offsets are in slot_t.spec */
+    /* records found by the inflate worker walking the block from the first offset that looks
+     * like the start of a record (offset 0 in htslib-written files, whose blocks start on record
+     * boundaries); their offsets are in slot_t.spec.  The list is only ever USED when the true
+     * chain arrives exactly at spec_start -- from there on the walk is the chain itself. */
+    uint32_t spec_start;
     uint32_t spec_n;
     uint32_t spec_end; /* where that walk stopped: isize, or the start of a record that runs on */
 } blk_t;
@@ -95,6 +98,7 @@ struct bam_reader {
     pthread_t producer, indexer, prefault;
     int producer_started, indexer_started, prefault_started;
     atomic_size_t scan_pos; /* how far the producer's block walk has got in the mapped input */
+    atomic_int n_ref_known; /* reference count once the header is parsed, -1 before (for the workers) */
     uint8_t *carry;    /* indexer's copy of the partial record a batch ended with */
     size_t carry_len, carry_cap;
     int stop;          /* guarded by mu */
@@ -158,8 +162,26 @@ static long bgzf_block_len(const uint8_t *p, size_t avail, uint32_t *xlen_out)
 
 /* ---- inflate workers ------------------------------------------------------------------------ */
 
+/* Does p[0 .. avail) look like the start of an alignment record?  The layout arithmetic of SAM
+ * spec 4.2 plus value ranges; used only to pick where a block's speculative walk starts. */
+static int plausible_record(const uint8_t *p, uint32_t avail, int32_t n_ref)
+{
+    if (avail < 36) return 0;
+    const uint32_t bs = le32(p);
+    const int32_t ref_id = (int32_t)le32(p + 4), pos = (int32_t)le32(p + 8);
+    const uint32_t l_name = p[12], n_cig = le16(p + 16), l_seq = le32(p + 20);
+    const int32_t next_ref = (int32_t)le32(p + 24), next_pos = (int32_t)le32(p + 28);
+    const int32_t ref_max = n_ref >= 0 ? n_ref : (1 << 24);
+    if (bs < 32 || bs > (1u << 26) || l_name == 0) return 0;
+    if (ref_id < -1 || ref_id >= ref_max || next_ref < -1 || next_ref >= ref_max || pos < -1 || next_pos < -1) return 0;
+    if (l_seq > bs) return 0;
+    if (32ull + l_name + 4ull * n_cig + ((uint64_t)l_seq + 1) / 2 + l_seq > bs) return 0;
+    if (36u + l_name <= avail && p[36 + l_name - 1] != 0) return 0; /* read name is NUL-terminated */
+    return 1;
+}
+
 /* inflates blocks of the current job until the shared counter runs past the table; every
- * block is then walked for records from its first byte (see blk_t.spec_n) */
+ * block is then walked for records (see blk_t.spec_start) */
 static void inflate_blocks(bam_reader *r, pss_inflater *inf)
 {
     slot_t *s = r->job_slot;
@@ -177,13 +199,29 @@ static void inflate_blocks(bam_reader *r, pss_inflater *inf)
                 atomic_store(&r->job_failed, 1);
                 continue;
             }
-            uint32_t *out = s->spec + b->uoff / 32, n = 0, o = 0;
-            while (o + 4 <= b->isize) {
-                const uint32_t bs = le32(dst + o);
-                if (bs < 32 || bs > b->isize - o - 4) break; /* not a record start, or it runs on */
-                out[n++] = (uint32_t)b->uoff + o;
-                o += 4 + bs;
+            /* first offset from which a chain of plausible records runs to the block's end
+             * (a few tries: a false start costs a walk, never correctness) */
+            const int32_t n_ref = atomic_load(&r->n_ref_known);
+            uint32_t *out = s->spec + b->uoff / 32, n = 0, o = 0, start = 0;
+            for (uint32_t c = 0, tries = 0; c + 36 <= b->isize && tries < 4; c++) {
+                if (!plausible_record(dst + c, b->isize - c, n_ref)) continue;
+                tries++;
+                n = 0;
+                o = c;
+                int good = 1;
+                while (o + 4 <= b->isize) {
+                    const uint32_t bs = le32(dst + o);
+                    if (bs < 32) { good = 0; break; }
+                    if (bs > b->isize - o - 4) break; /* runs on into the next block */
+                    if (n && !plausible_record(dst + o, b->isize - o, n_ref)) { good = 0; break; }
+                    out[n++] = (uint32_t)b->uoff + o;
+                    o += 4 + bs;
+                }
+                if (good && n) { start = c; break; }
+                n = 0;
+                o = 0;
             }
+            b->spec_start = start;
             b->spec_n = n;
             b->spec_end = o;
         }
@@ -267,7 +305,7 @@ static int fill_slot(bam_reader *r, slot_t *s)
             s->blk = nb;
             s->blk_cap = cap;
         }
-        s->blk[s->n_blk++] = (blk_t){r->cpos, (uint32_t)bl, xlen, isize, uoff, 0, 0};
+        s->blk[s->n_blk++] = (blk_t){r->cpos, (uint32_t)bl, xlen, isize, uoff, 0, 0, 0};
         uoff += isize;
         r->cpos += (size_t)bl;
     }
@@ -311,6 +349,7 @@ static int parse_header(bam_reader *r, const uint8_t *p, size_t len, int input_d
     }
     *end_out = o;
     r->hdr_parsed = 1;
+    atomic_store(&r->n_ref_known, r->hdr.n_ref);
     return 0;
 }
 
@@ -342,7 +381,7 @@ static int index_slot(bam_reader *r, slot_t *s)
     int stop = 0;
     while (!stop && o + 4 <= len) {
         while (b < s->n_blk && s->blk[b].uoff + s->blk[b].isize <= o) b++;
-        if (b < s->n_blk && s->blk[b].uoff == o && s->blk[b].spec_n) {
+        if (b < s->n_blk && s->blk[b].spec_n && s->blk[b].uoff + s->blk[b].spec_start == o) {
             const blk_t *k = &s->blk[b];
             if (offs_reserve(r, s, n + k->spec_n + 2)) return -1;
             const uint32_t *src = s->spec + k->uoff / 32;
@@ -556,6 +595,7 @@ bam_reader *bam_reader_open(const char *path, int n_threads, size_t batch_bytes,
     if (!r) return NULL;
     r->fd = -1;
     r->held = -1;
+    atomic_store(&r->n_ref_known, -1);
     pthread_mutex_init(&r->mu, NULL);
     pthread_cond_init(&r->cv, NULL);
     pthread_mutex_init(&r->job_mu, NULL);
