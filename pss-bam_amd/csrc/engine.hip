@@ -81,7 +81,8 @@ struct pssbam_engine {
     bool has_rg = false;
     int device = 0;
     int n_cu = 0;
-    hipStream_t stream = nullptr, copy_stream = nullptr;
+    hipStream_t stream = nullptr, copy_stream = nullptr, copy_stream2 = nullptr;
+    hipEvent_t copied2 = nullptr;   // second half of a split H2D copy
     bool own_stream = false;
 
     // genome
@@ -186,6 +187,8 @@ extern "C" int pssbam_engine_create(const pssbam_config *cfg, pssbam_engine **ou
     e->n_cu = pr.multiProcessorCount;
     HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&e->copy_stream2, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&e->copied2, hipEventDisableTiming));
     e->own_stream = true;
     HIP_TRY(hipEventCreate(&e->t_begin));
     HIP_TRY(hipEventCreate(&e->t_end));
@@ -222,6 +225,7 @@ extern "C" void pssbam_engine_destroy(pssbam_engine *e) {
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->copy_stream) (void)hipStreamSynchronize(e->copy_stream);
+    if (e->copy_stream2) (void)hipStreamSynchronize(e->copy_stream2);
     for (Slot &s : e->slots) {
         if (s.d_recs) (void)hipFree(s.d_recs);
         if (s.d_offs) (void)hipFree(s.d_offs);
@@ -240,6 +244,8 @@ extern "C" void pssbam_engine_destroy(pssbam_engine *e) {
     if (e->d_counters_own) (void)hipFree(e->d_counters_own);
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
     if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
+    if (e->copy_stream2) (void)hipStreamDestroy(e->copy_stream2);
+    if (e->copied2) (void)hipEventDestroy(e->copied2);
     delete e;
 }
 
@@ -614,9 +620,17 @@ extern "C" int pssbam_engine_submit(pssbam_engine *e, const void *records, uint6
         HIP_TRY(hipMalloc(&s.d_offs, s.offs_cap * sizeof(uint32_t)));
     }
     // H2D on the copy stream so it overlaps the previous block's kernel
-    HIP_TRY(hipMemcpyAsync(s.d_recs, records, nbytes, hipMemcpyHostToDevice, e->copy_stream));
+    // large blocks go over two copy streams (two DMA engines): one stream alone does not fill
+    // the PCIe link
+    const uint64_t half = (nbytes >= (64ull << 20) && !getenv("PSSBAM_ONE_COPY_STREAM")) ? (nbytes / 2) & ~4095ull : 0;
+    if (half) {
+        HIP_TRY(hipMemcpyAsync(s.d_recs + half, (const uint8_t *)records + half, nbytes - half, hipMemcpyHostToDevice, e->copy_stream2));
+        HIP_TRY(hipEventRecord(e->copied2, e->copy_stream2));
+    }
+    HIP_TRY(hipMemcpyAsync(s.d_recs, records, half ? half : nbytes, hipMemcpyHostToDevice, e->copy_stream));
     HIP_TRY(hipMemcpyAsync(s.d_offs, offsets, ((size_t)n_records + 1) * sizeof(uint32_t), hipMemcpyHostToDevice,
                            e->copy_stream));
+    if (half) HIP_TRY(hipStreamWaitEvent(e->copy_stream, e->copied2, 0));  // `copied` then covers both halves
     HIP_TRY(hipEventRecord(s.copied, e->copy_stream));
     HIP_TRY(hipStreamWaitEvent(e->stream, s.copied, 0));
     rc = launch_tally(e, s.d_recs, nbytes, s.d_offs, n_records, (const uint8_t *)records, nbytes);
@@ -631,6 +645,7 @@ extern "C" int pssbam_engine_submit(pssbam_engine *e, const void *records, uint6
 extern "C" int pssbam_engine_sync(pssbam_engine *e) {
     if (!e) return fail(PSSBAM_EINVAL, "null engine");
     HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->copy_stream2));
     HIP_TRY(hipStreamSynchronize(e->copy_stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     return PSSBAM_OK;

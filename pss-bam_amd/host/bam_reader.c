@@ -603,6 +603,7 @@ bam_reader *bam_reader_open(const char *path, int n_threads, size_t batch_bytes,
     pthread_cond_init(&r->done_cv, NULL);
     if (load_input(r, path)) goto fail;
 
+    if (n_threads <= 0 && getenv("PSSBAM_INFLATE_THREADS")) n_threads = atoi(getenv("PSSBAM_INFLATE_THREADS"));
     if (n_threads <= 0) {
         long n = sysconf(_SC_NPROCESSORS_ONLN);
         n_threads = n > 32 ? 32 : (n < 1 ? 1 : (int)n);
