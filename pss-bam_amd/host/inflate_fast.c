@@ -208,7 +208,7 @@ typedef struct {
 /* Decodes literal/length + distance symbols of one Huffman block until its end-of-block code.
  * FAST = 1: no per-symbol bounds checks -- valid while >= 16 input bytes and >= 280 output
  * bytes remain (one iteration consumes <= 12 bytes and produces <= 3 literals or a 258-byte
- * match plus 7 bytes of copy slack); returns 1 when that margin is used up and the caller must
+ * match plus 15 bytes of copy slack); returns 1 when that margin is used up and the caller must
  * continue with FAST = 0, which checks everything.  0 = end of block, negative = error. */
 static inline __attribute__((always_inline)) int run_codes(const pss_inflater *st, dstate *d, const int FAST)
 {
@@ -251,25 +251,44 @@ static inline __attribute__((always_inline)) int run_codes(const pss_inflater *s
             FINISH(0);
         }
         if (E_KIND(e) != K_LEN) FINISH(PSS_INF_BAD_SYMBOL);
-        /* match: length (<= 15 + 5 bits), then distance (<= 15 + 13 bits): 48 <= 56 */
-        XDROP(E_LEN(e));
+        /* match: length (<= 15 + 5 bits), then distance (<= 15 + 13 bits): 48 <= 56.  All fields are
+         * cut out of the SAME bit buffer at running offsets and dropped once, which keeps the
+         * dependency chain to  entry -> offset -> entry  instead of four buffer updates. */
+        unsigned used = E_LEN(e);
         unsigned xb = (e >> 8) & 0xFFu;
-        const size_t len = (e >> 16) + BITS(xb);
-        XDROP(xb);
-        uint32_t dd = st->ds[bb & ds_mask];
-        if (E_KIND(dd) == K_LONG) dd = decode_long(TT_DS, bb, st->ds_count, st->ds_sorted);
+        const size_t len = (e >> 16) + (unsigned)((bb >> used) & ((1ull << xb) - 1ull));
+        used += xb;
+        uint32_t dd = st->ds[(bb >> used) & ds_mask];
+        if (E_KIND(dd) == K_LONG) dd = decode_long(TT_DS, bb >> used, st->ds_count, st->ds_sorted);
         if (E_KIND(dd) != K_LEN) FINISH(PSS_INF_BAD_SYMBOL);
-        XDROP(E_LEN(dd));
+        used += E_LEN(dd);
         xb = (dd >> 8) & 0xFFu;
-        const size_t dist = (dd >> 16) + BITS(xb);
-        XDROP(xb);
+        const size_t dist = (dd >> 16) + (unsigned)((bb >> used) & ((1ull << xb) - 1ull));
+        used += xb;
+        XDROP(used);
         if (dist > (size_t)(out - out0)) FINISH(PSS_INF_BAD_DISTANCE);
         if (!FAST && len > (size_t)(out_end - out)) FINISH(PSS_INF_OVERRUN);
         const uint8_t *src = out - dist;
         uint8_t *const stop = out + len;
-        if (dist >= 8 && (FAST || (size_t)(out_end - out) >= len + 8)) {
-            /* 8 bytes at a time; may scribble up to 7 bytes past `stop`, still inside the
-             * block's own output, which later symbols overwrite */
+        if (dist >= 16 && (FAST || (size_t)(out_end - out) >= len + 16)) {
+            /* 16 bytes at a time (two words; source and destination chunks cannot overlap); may
+             * scribble up to 15 bytes past `stop`, still inside the block's own output, which
+             * later symbols overwrite.  Most matches are done after the first chunk or two. */
+            memcpy(out, src, 16);
+            if (len > 16) {
+                memcpy(out + 16, src + 16, 16);
+                if (len > 32) {
+                    out += 32;
+                    src += 32;
+                    do {
+                        memcpy(out, src, 16);
+                        out += 16;
+                        src += 16;
+                    } while (out < stop);
+                }
+            }
+            out = stop;
+        } else if (dist >= 8 && (FAST || (size_t)(out_end - out) >= len + 8)) {
             do {
                 memcpy(out, src, 8);
                 out += 8;

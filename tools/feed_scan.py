@@ -25,8 +25,8 @@ fa, bam = tmp / "ref.fa", tmp / "reads.bam"
 threads = os.cpu_count() or 8
 synth.fasta_host(cfg, fa, threads=threads)
 synth.bam_file_host(cfg, 0, reads, bam, level=1, threads=threads)
-for env in ({"PSSBAM_INFLATE_THREADS": "32"}, {"PSSBAM_INFLATE_THREADS": "48"}, {"PSSBAM_INFLATE_THREADS": "64"},
-            {"PSSBAM_INFLATE_THREADS": "32", "PSSBAM_ONE_COPY_STREAM": "1"}, {"PSSBAM_INFLATE_THREADS": "64", "PSSBAM_ONE_COPY_STREAM": "1"}):
+settings = [{"PSSBAM_INFLATE_THREADS": t} for t in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["32", "48", "64"])]
+for env in settings:
     for rep in range(2):
         t = time.time()
         pr = subprocess.run([str(pkg.PKG_DIR / "bin" / "pss-bam"), "-F", str(fa), "-B", str(bam), "-o", str(tmp / "out"), "-r", str(region_len)],
