@@ -8,6 +8,7 @@
  */
 #include "inflate_fast.h"
 
+#include <stdlib.h>
 #include <string.h>
 
 enum { K_BAD = 0, K_LIT = 1, K_LEN = 2, K_EOB = 3, K_LONG = 4 };
@@ -370,8 +371,9 @@ int pss_inflate_raw(pss_inflater *st, const uint8_t *in, size_t in_len, uint8_t 
 /* ------------------------------------------------------------------------------------------ */
 
 static uint32_t crc_tab[8][256];
-static int crc_use_clmul = 0;
+static int crc_use_clmul = 0, crc_use_vclmul = 0;
 static int have_clmul(void);
+static int have_vclmul(void);
 
 /* tables and CPU probe once, at load time: no lazy initialisation for threads to race on */
 __attribute__((constructor)) static void crc_init(void)
@@ -384,6 +386,7 @@ __attribute__((constructor)) static void crc_init(void)
     for (uint32_t i = 0; i < 256; i++)
         for (int t = 1; t < 8; t++) crc_tab[t][i] = (crc_tab[t - 1][i] >> 8) ^ crc_tab[0][crc_tab[t - 1][i] & 0xFFu];
     crc_use_clmul = have_clmul();
+    crc_use_vclmul = have_vclmul() && !getenv("PSSBAM_NO_AVX512");
 }
 
 static uint32_t crc_slice8(uint32_t c, const uint8_t *p, size_t n)
@@ -406,6 +409,7 @@ static uint32_t crc_slice8(uint32_t c, const uint8_t *p, size_t n)
 }
 
 #if defined(__x86_64__)
+#include <cpuid.h>
 #include <immintrin.h>
 
 /* Folding with carry-less multiplication (Gopal et al., "Fast CRC Computation for Generic
@@ -471,7 +475,54 @@ static int have_clmul(void)
     __builtin_cpu_init();
     return __builtin_cpu_supports("pclmul") && __builtin_cpu_supports("sse4.1");
 }
+
+/* The same folding 256 bytes at a time: four 512-bit accumulators = sixteen 128-bit lanes, each
+ * folded across 2048 bits with x^(2048+32), x^(2048-32) mod P (same derivation as the constants
+ * above: bit-reflected remainder shifted left by one).  When fewer than 256 bytes are left the
+ * sixteen lanes ARE a 256-byte message congruent to everything consumed so far, so they are
+ * handed, followed by the tail, to the 128-bit routine.  len >= 512. */
+__attribute__((target("avx512f,avx512vl,vpclmulqdq,pclmul,sse4.1"))) static uint32_t crc_vclmul(uint32_t crc, const uint8_t *p, size_t len)
+{
+    const __m512i k = _mm512_broadcast_i32x4(_mm_set_epi64x(0x01322d1430ll, 0x011542778all));
+    __m512i x0 = _mm512_loadu_si512(p), x1 = _mm512_loadu_si512(p + 64), x2 = _mm512_loadu_si512(p + 128), x3 = _mm512_loadu_si512(p + 192);
+    x0 = _mm512_xor_si512(x0, _mm512_zextsi128_si512(_mm_cvtsi32_si128((int)crc)));
+    p += 256;
+    len -= 256;
+    while (len >= 256) {
+        const __m512i h0 = _mm512_clmulepi64_epi128(x0, k, 0x11), h1 = _mm512_clmulepi64_epi128(x1, k, 0x11);
+        const __m512i h2 = _mm512_clmulepi64_epi128(x2, k, 0x11), h3 = _mm512_clmulepi64_epi128(x3, k, 0x11);
+        x0 = _mm512_clmulepi64_epi128(x0, k, 0x00);
+        x1 = _mm512_clmulepi64_epi128(x1, k, 0x00);
+        x2 = _mm512_clmulepi64_epi128(x2, k, 0x00);
+        x3 = _mm512_clmulepi64_epi128(x3, k, 0x00);
+        x0 = _mm512_ternarylogic_epi64(x0, h0, _mm512_loadu_si512(p), 0x96);
+        x1 = _mm512_ternarylogic_epi64(x1, h1, _mm512_loadu_si512(p + 64), 0x96);
+        x2 = _mm512_ternarylogic_epi64(x2, h2, _mm512_loadu_si512(p + 128), 0x96);
+        x3 = _mm512_ternarylogic_epi64(x3, h3, _mm512_loadu_si512(p + 192), 0x96);
+        p += 256;
+        len -= 256;
+    }
+    uint8_t tail[256 + 256] __attribute__((aligned(64)));
+    _mm512_store_si512(tail, x0);
+    _mm512_store_si512(tail + 64, x1);
+    _mm512_store_si512(tail + 128, x2);
+    _mm512_store_si512(tail + 192, x3);
+    const size_t whole = len & ~(size_t)15;
+    memcpy(tail + 256, p, whole);
+    return crc_slice8(crc_clmul(0u, tail, 256 + whole), p + whole, len - whole);
+}
+
+static int have_vclmul(void)
+{
+    unsigned a, b, c, d;
+    __builtin_cpu_init();
+    if (!__builtin_cpu_supports("avx512f") || !__builtin_cpu_supports("avx512vl") || !have_clmul()) return 0; /* includes OS support for ZMM state */
+    if (!__get_cpuid_count(7, 0, &a, &b, &c, &d)) return 0;
+    return (c >> 10) & 1u; /* CPUID.7.0:ECX.VPCLMULQDQ */
+}
 #else
+static int have_vclmul(void) { return 0; }
+static uint32_t crc_vclmul(uint32_t crc, const uint8_t *p, size_t len) { (void)p; (void)len; return crc; }
 static int have_clmul(void) { return 0; }
 static uint32_t crc_clmul(uint32_t crc, const uint8_t *p, size_t len) { (void)p; (void)len; return crc; }
 #endif
@@ -479,6 +530,7 @@ static uint32_t crc_clmul(uint32_t crc, const uint8_t *p, size_t len) { (void)p;
 uint32_t pss_crc32(uint32_t crc, const uint8_t *buf, size_t len)
 {
     uint32_t c = ~crc;
+    if (len >= 512 && crc_use_vclmul) return ~crc_vclmul(c, buf, len);
     if (len >= 64 && crc_use_clmul) {
         const size_t body = len & ~(size_t)15;
         c = crc_clmul(c, buf, body);
