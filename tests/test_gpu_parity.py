@@ -60,7 +60,7 @@ def _check_pss(got, want_fwd, want_rev, st):
     assert got.stats["pss_filtered"] == st[tl.ST_FILTERED]
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PSSBAM_FUZZ_SEEDS", "8"))))   # more seeds for a soak run
 def test_fuzz_both_kernels_match_oracle(pkg, oracle, tmp_path, seed):
     """random records x random options, text for the oracle / binary for the engine, the
     two encodings written independently from the same record list"""
