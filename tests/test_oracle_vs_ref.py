@@ -4,6 +4,8 @@
 Skipped when oracle/_ref is absent (a checkout that never saw /root/reference); the
 golden-vector test (test_golden.py) pins the oracle in that case.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -23,7 +25,7 @@ def _dataset(tmp_path, seed, n=1500, **kw):
     return fa, sam, recs, refs
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PSSBAM_FUZZ_SEEDS", "12"))))
 def test_pss_restatement_matches_reference(tmp_path, oracle, seed):
     fa, sam, _, _ = _dataset(tmp_path, seed)
     rng = np.random.default_rng(1000 + seed)
@@ -53,7 +55,7 @@ def test_pss_counts_are_nontrivial(tmp_path, oracle):
     assert st[1] > 0 and st[2] > 0 and st[3] > 0        # parse-skip, no-contig, filtered all occur
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PSSBAM_FUZZ_SEEDS", "12"))))
 def test_fragkon_restatement_matches_reference(tmp_path, oracle, seed):
     contigs, refs, recs = fuzz_dataset(100 + seed, 1500)
     rng = np.random.default_rng(2000 + seed)
