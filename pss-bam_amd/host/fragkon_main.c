@@ -71,7 +71,7 @@ int main(int argc, char *argv[])
         fprintf(stderr, "    *** k is odd - counting %d bases outside %d bases inside of alignment.\n", klen / 2,
                 klen / 2 + 1);
     fprintf(stderr, "Reading genome sequence from: %s\n", fasta_fn);
-    frontend_warmup_start();   /* HIP start-up overlaps the FASTA load */
+    frontend_warmup_start(bam_fn);   /* HIP start-up overlaps the FASTA load */
     Genome *genome = init_genome(fasta_fn);
     if (!genome) {
         fprintf(stderr, "Error: Unable to load genome from %s.\n", fasta_fn);

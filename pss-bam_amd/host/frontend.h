@@ -26,9 +26,11 @@ int run_tally(const pssbam_config *cfg, Genome *genome, const char *aln_path, in
  * unless $PSSBAM_CLEAN_EXIT is), run_tally() leaves engines, pinned slots and the mapped input
  * to process exit instead of releasing ~4 GB piece by piece (0.12 s of a 0.7 s command), and
  * front_end_exit() ends the process without running destructors. */
-/* Starts bringing up the HIP runtime + device contexts on a helper thread (returns at once):
- * call it before the FASTA is loaded so the two overlap. */
-void frontend_warmup_start(void);
+/* Start-up work that overlaps the caller's FASTA load (returns at once): opens the BAM reader
+ * early if aln_path is a BGZF BAM -- it starts inflating its first batches immediately -- and, on a
+ * helper thread, brings up the HIP runtime + device contexts and page-locks the reader's slots.
+ * run_tally() picks all of it up.  aln_path may be NULL. */
+void frontend_warmup_start(const char *aln_path);
 
 extern int frontend_fast_exit;
 void front_end_exit(int status);

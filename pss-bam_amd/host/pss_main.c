@@ -84,7 +84,7 @@ int main(int argc, char *argv[])
     fprintf(stderr, " -U %s -D %s%s\n", up_ctx, down_ctx, merged_only ? " -m" : "");
 
     fprintf(stderr, "Reading genome sequence from:\n%s\n", fasta_fn);
-    frontend_warmup_start();   /* HIP start-up overlaps the FASTA load */
+    frontend_warmup_start(bam_fn);   /* HIP start-up overlaps the FASTA load */
     Genome *genome = init_genome(fasta_fn);
     if (!genome) {
         fprintf(stderr, "Error: Unable to load genome from %s.\n", fasta_fn);
