@@ -526,6 +526,7 @@ static int launch_tally(pssbam_engine *e, const uint8_t *d_recs, uint64_t nbytes
         if (e->env_tile_reads > 0) T = std::min<uint32_t>(TILED_MAX_T, (uint32_t)(e->env_tile_reads + 15) / 16 * 16);
         P.reads_per_tile = T;
         P.prefix_pieces = pieces;
+        P.xcd_map = (uint32_t)env_int("PSSBAM_XCD_MAP");
         P.ablate = (uint32_t)env_int("PSSBAM_ABLATE");  // profiling aid (tools/ablate.sh): switches kernel phases off
         if (P.ablate && !e->warned_ablate) {
             fprintf(stderr, "[pssbam] PSSBAM_ABLATE=%u: kernel phases are switched off, the tables are WRONG (profiling only)\n", P.ablate);

@@ -64,6 +64,7 @@ struct TallyParams {
     uint32_t reads_per_tile;      // T, multiple of 64
     uint32_t prefix_pieces;       // 16-byte pieces of each record the tiled kernel stages in LDS
     uint32_t row_base;            // tiled kernel: this launch tallies table rows row_base .. row_base+31
+    uint32_t xcd_map;             // tiled kernel: XCD-contiguous workgroup -> tile mapping
     uint32_t ablate;              // diagnostics: phases to skip (results are wrong when non-zero)
     uint32_t *scratch;            // tiled kernel: per-workgroup partial tables (SCRATCH_WORDS each)
 };

@@ -296,14 +296,23 @@ __device__ __forceinline__ void tally_tiled_body(const TallyParams &P, const Tal
     const uint32_t n_ref_cached = min((uint32_t)P.n_ref, REF_LDS_ENTRIES);
     if (tid < n_ref_cached) refs_lds[tid] = P.ref_info[tid];
     if (tid == n_ref_cached) refs_lds[tid] = P.ref_info[P.n_ref];
-    const uint32_t n_tiles = (P.n_recs + T - 1u) / T;
-    const uint32_t tstride = gridDim.x;
+    const uint32_t all_tiles = (P.n_recs + T - 1u) / T;
+    // Workgroup -> tiles.  Workgroups are dealt to the 8 XCDs round-robin (blockIdx & 7); with
+    // xcd_map every XCD walks its own contiguous eighth of the block, so neighbouring tiles -- which
+    // share reference lines and the record line at their seam -- meet in the same L2.
+    uint32_t tile0 = blockIdx.x, tstride = gridDim.x, n_tiles = all_tiles;
+    if (P.xcd_map && (gridDim.x & 7u) == 0u && all_tiles >= 64u) {
+        const uint32_t per = (all_tiles + 7u) >> 3, xcd = blockIdx.x & 7u;
+        tile0 = xcd * per + (blockIdx.x >> 3);
+        tstride = gridDim.x >> 3;
+        n_tiles = min(all_tiles, (xcd + 1u) * per);
+    }
     // software pipeline over this workgroup's tiles k0, k0+stride, ...:
     //   toffs[par]      offsets of the tile being processed, toffs[par^1] those of the next one
     //                   (written from VGPRs that were loaded one tile earlier)
     //   stage           pieces of the tile being processed; refilled for the next tile as soon as
     //                   CODES-A has read everything it needs
-    uint32_t tile = blockIdx.x;
+    uint32_t tile = tile0;
     uint32_t off_a = 0;
     const uint32_t TOFF = TILED_MAX_T + 4u;  // stride between the two offset buffers
     auto load_offsets = [&](uint32_t t) {
