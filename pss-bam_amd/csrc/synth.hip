@@ -51,8 +51,8 @@ __global__ void k_offsets_linear(uint32_t *offs, uint64_t n_plus_1, uint32_t rec
 // helpers
 // ---------------------------------------------------------------------------------------
 template <class F>
-static void parallel_for(uint64_t n, int threads, F f) {
-    if (threads <= 1 || n < 4096) { f(0, n); return; }
+static void parallel_for(uint64_t n, int threads, F f, uint64_t min_n = 4096) {
+    if (threads <= 1 || n < min_n) { f(0, n); return; }
     std::vector<std::thread> th;
     const uint64_t per = (n + threads - 1) / threads;
     for (int t = 0; t < threads; t++) {
@@ -248,7 +248,7 @@ int synth_bam_file_host(const synth_cfg *c, uint64_t slot0, uint64_t n, const ch
             put32((uint32_t)c->contig_len[k]);
         }
     }
-    const uint64_t CHUNK_READS = 1u << 18;  // records generated + compressed per round
+    const uint64_t CHUNK_READS = 1u << 20;  // records generated + compressed per round
     const size_t BLK = 0xFF00;
     std::vector<uint8_t> raw, carry(head.begin(), head.end());
     std::vector<uint32_t> sizes, offs;
@@ -288,11 +288,12 @@ int synth_bam_file_host(const synth_cfg *c, uint64_t slot0, uint64_t n, const ch
         const size_t n_blk = cut.size() - 1;
         std::vector<std::vector<uint8_t>> out(n_blk);
         parallel_for(n_blk, threads, [&](uint64_t b0, uint64_t b1) {
-            z_stream zs;
+            z_stream zs;   // one deflate state per worker, reset per block (deflateInit2 clears ~260 KB each time)
+            memset(&zs, 0, sizeof zs);
+            deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
             for (uint64_t b = b0; b < b1; b++) {
                 const size_t o = cut[b], len = cut[b + 1] - cut[b];
-                memset(&zs, 0, sizeof zs);
-                deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
+                deflateReset(&zs);
                 std::vector<uint8_t> &dst = out[b];
                 dst.resize(18 + deflateBound(&zs, len) + 8);
                 zs.next_in = raw.data() + o;
@@ -301,7 +302,6 @@ int synth_bam_file_host(const synth_cfg *c, uint64_t slot0, uint64_t n, const ch
                 zs.avail_out = (uInt)(dst.size() - 26);
                 deflate(&zs, Z_FINISH);
                 const size_t clen = zs.total_out;
-                deflateEnd(&zs);
                 const uint8_t hdr[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
                 memcpy(dst.data(), hdr, 16);
                 const uint32_t bsize = (uint32_t)(clen + 25), crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), raw.data() + o, (uInt)len);
@@ -310,7 +310,8 @@ int synth_bam_file_host(const synth_cfg *c, uint64_t slot0, uint64_t n, const ch
                 for (int i = 0; i < 4; i++) { t[i] = (uint8_t)(crc >> (8 * i)); t[4 + i] = (uint8_t)((uint32_t)len >> (8 * i)); }
                 dst.resize(18 + clen + 8);
             }
-        });
+            deflateEnd(&zs);
+        }, 64);   // a block is ~64 KiB of deflate work: worth a thread from a few dozen on
         for (auto &d : out)
             if (fwrite(d.data(), 1, d.size(), f) != d.size()) rc = -1;
         carry.assign(raw.begin() + cut.back(), raw.end());

@@ -804,7 +804,7 @@ long bam_record_to_sam(const uint8_t *rec, uint32_t rec_len, const bam_header *h
     sb_puts(&s, l_name > 1 ? (const char *)rec + 36 : "*");
     sb_printf(&s, "\t%u\t", flag);
     sb_puts(&s, (ref_id >= 0 && ref_id < h->n_ref) ? h->ref_name[ref_id] : "*");
-    sb_printf(&s, "\t%d\t%u\t", pos + 1, mapq);
+    sb_printf(&s, "\t%lld\t%u\t", (long long)pos + 1, mapq); /* 64-bit: pos may be INT_MAX in a hostile file */
     if (n_cig == 0) sb_putc(&s, '*');
     for (uint32_t k = 0; k < n_cig; k++) {
         uint32_t c = le32(rec + cig + 4 * k);
@@ -815,7 +815,7 @@ long bam_record_to_sam(const uint8_t *rec, uint32_t rec_len, const bam_header *h
     if (nref < 0) sb_putc(&s, '*');
     else if (nref == ref_id) sb_putc(&s, '=');
     else sb_puts(&s, nref < h->n_ref ? h->ref_name[nref] : "*");
-    sb_printf(&s, "\t%d\t%d\t", npos + 1, tlen);
+    sb_printf(&s, "\t%lld\t%d\t", (long long)npos + 1, tlen);
     if (l_seq == 0) sb_putc(&s, '*');
     for (uint32_t j = 0; j < l_seq; j++) {
         uint8_t b = rec[seq + (j >> 1)];

@@ -61,12 +61,13 @@ void front_end_exit(int status)
     exit(status);
 }
 
-static double now_s(void)
+double frontend_now_s(void)
 {
     struct timespec ts;
     clock_gettime(CLOCK_MONOTONIC, &ts);
     return ts.tv_sec + ts.tv_nsec * 1e-9;
 }
+#define now_s frontend_now_s
 
 int env_gpu_count(void)
 {

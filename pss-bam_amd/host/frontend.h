@@ -35,5 +35,6 @@ void frontend_warmup_start(const char *aln_path);
 extern int frontend_fast_exit;
 void front_end_exit(int status);
 void run_result_free(run_result *res);
+double frontend_now_s(void); /* CLOCK_MONOTONIC seconds */
 int env_gpu_count(void); /* PSSBAM_NGPU, default 1, clamped to the devices present */
 #endif

@@ -11,6 +11,7 @@
 
 #include "fasta-genome-io.h"
 #include "pssbam_hip.h"
+#include "report.h"
 
 #define K_DEF (4)
 
@@ -59,12 +60,7 @@ int main(int argc, char *argv[])
         fprintf(stderr, "Error: GPU engine: %s\n", pssbam_last_error());
         return 1;
     }
-    char kmer[16];
-    kmer[k] = '\0';
-    for (size_t b = 0; b < bins; b++) {
-        for (int i = 0; i < k; i++) kmer[i] = "ACGT"[(b >> (2 * (k - 1 - i))) & 3u];
-        printf("%s\t%u\n", kmer, counts[b] > UINT_MAX ? UINT_MAX : (unsigned int)counts[b]);
-    }
+    gkc_write_table(stdout, k, counts);
     pssbam_engine_destroy(eng);
     destroy_genome(genome);
     free(counts);

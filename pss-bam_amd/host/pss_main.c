@@ -85,7 +85,9 @@ int main(int argc, char *argv[])
 
     fprintf(stderr, "Reading genome sequence from:\n%s\n", fasta_fn);
     frontend_warmup_start(bam_fn);   /* HIP start-up overlaps the FASTA load */
+    const double t_fa = frontend_now_s();
     Genome *genome = init_genome(fasta_fn);
+    if (getenv("PSSBAM_STATS")) fprintf(stderr, "[pssbam] genome: fasta load %.3f s\n", frontend_now_s() - t_fa);
     if (!genome) {
         fprintf(stderr, "Error: Unable to load genome from %s.\n", fasta_fn);
         exit(1);

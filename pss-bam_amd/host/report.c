@@ -122,3 +122,18 @@ int fragkon_write_table(FILE *out, const char *fasta_fn, const char *bam_fn, int
     }
     return 0;
 }
+
+/* genome-kmer-count's table (/root/reference/genome-kmer-count.c:56-66 prints kmer2count(): an
+ * unsigned int that sticks at UINT_MAX, kmer.c:102-104) */
+int gkc_write_table(FILE *out, int klen, const uint64_t *counts)
+{
+    const uint64_t bins = (uint64_t)1 << (2 * klen);
+    char kmer[40];
+    if (klen < 1 || klen > 31) return 1;
+    kmer[klen] = '\0';
+    for (uint64_t b = 0; b < bins; b++) {
+        for (int i = 0; i < klen; i++) kmer[i] = "ACGT"[(b >> (2 * (klen - 1 - i))) & 3u];
+        fprintf(out, "%s\t%u\n", kmer, counts[b] > UINT_MAX ? UINT_MAX : (unsigned int)counts[b]);
+    }
+    return 0;
+}

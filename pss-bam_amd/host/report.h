@@ -13,4 +13,6 @@ int pss_write_rates(const char *fasta_fn, const char *bam_fn, const char *out_pr
 /* k5 / k3: 4^klen 64-bit bins (clamped to UINT_MAX on output) */
 int fragkon_write_table(FILE *out, const char *fasta_fn, const char *bam_fn, int klen, const uint64_t *k5,
                         const uint64_t *k3);
+/* counts: 4^klen 64-bit bins (clamped to UINT_MAX on output) */
+int gkc_write_table(FILE *out, int klen, const uint64_t *counts);
 #endif

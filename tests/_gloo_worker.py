@@ -3,7 +3,9 @@
 Exercises bench.py's N>1 plumbing -- shard_of() and reduce_counters() -- without a GPU: each
 rank tallies ITS slot range of one synthetic stream (with the oracle standing in for the
 device: the same u64 counter block layout [fwd | rev | k5 | k3]) and the blocks are summed
-onto rank 0, where the result must equal the oracle's tables for the whole stream."""
+onto rank 0, where the result must equal the oracle's tables for the whole stream.
+argv[1] = shard plan ("weak": 4000 reads per rank, "strong": 9001 reads in total -- not a
+multiple of 2 or 3, so the ranges are uneven)."""
 import os
 import sys
 import tempfile
@@ -27,10 +29,17 @@ def main():
     rank, world = dist.get_rank(), dist.get_world_size()
     ge.load_pkg()
     from pss_bam_amd import synth
-    per_rank = 4000
+    plan = sys.argv[1] if len(sys.argv) > 1 else "weak"
+    reads_arg = 4000 if plan == "weak" else 9001
     d = synth.config("C4", scale_genome=0.0003)
     region_len = d.pop("region_len")
-    d["n_reads"], slot0, n = bench.shard_of(rank, world, per_rank)
+    d["n_reads"], slot0, n = bench.shard_of(rank, world, reads_arg, plan)
+    total = d["n_reads"]
+    # the plan must tile the stream: contiguous, disjoint, complete
+    spans = [bench.shard_of(r, world, reads_arg, plan) for r in range(world)]
+    assert all(sp[0] == total for sp in spans) and spans[0][1] == 0
+    assert all(spans[r][1] + spans[r][2] == spans[r + 1][1] for r in range(world - 1))
+    assert spans[-1][1] + spans[-1][2] == total
     cfg = synth.make_cfg(**d)
     tmp = Path(tempfile.mkdtemp(prefix=f"gloo{rank}_"))
     fa, sam = tmp / "g.fa", tmp / "shard.sam"
@@ -48,7 +57,7 @@ def main():
     bench.reduce_counters(ctr, world)
     if rank == 0:
         whole = tmp / "whole.sam"
-        synth.sam_host(cfg, 0, per_rank * world, whole)
+        synth.sam_host(cfg, 0, total, whole)
         wf, wr, _ = orc.pss(g, whole, po)
         w5, w3, _ = orc.fragkon(g, whole, ko)
         want = np.concatenate([wf.ravel(), wr.ravel(), w5.astype(np.uint64), w3.astype(np.uint64)])
@@ -57,7 +66,7 @@ def main():
         got = ctr.numpy().view(np.uint64)
         assert np.array_equal(got, want), "sharded sum differs from the whole-stream tally"
         assert wf.sum() > 1000
-        print("GLOO_SHARD_OK", world, flush=True)
+        print("GLOO_SHARD_OK", plan, world, flush=True)
     orc.free_genome(g)
     dist.barrier()
     dist.destroy_process_group()

@@ -593,3 +593,37 @@ def test_bam_reader_block_layouts(host, tmp_path):
                 env["PSSBAM_BATCH_BYTES"] = batch
             got = subprocess.run([str(exe), str(bam)], capture_output=True, text=True, check=True, env=env).stdout
             assert got == want, (ragged, batch)
+
+
+def test_kmer_count_saturates_at_uint_max_on_print(host, tmp_path):
+    """The reference's k-mer bins are `unsigned int` that stick at UINT_MAX (kmer.c:102-104); the
+    device bins are u64 and the printers clamp.  A bin of 2^32+5 must print as 4294967295 in both
+    tables (fragkon.c:231-249, genome-kmer-count.c:56-66), its neighbours untouched."""
+    L, _ = host
+    libc = C.CDLL(None)
+    libc.fopen.restype = C.c_void_p
+    libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+    libc.fclose.argtypes = [C.c_void_p]
+    L.fragkon_write_table.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.gkc_write_table.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    k = 3
+    k5 = np.arange(4 ** k, dtype=np.uint64)
+    k3 = np.zeros(4 ** k, dtype=np.uint64)
+    k5[7] = (1 << 32) + 5
+    k5[8] = (1 << 32) - 1            # exactly UINT_MAX: printed as is
+    k3[9] = 1 << 40
+    k3[10] = (1 << 32) - 2
+    f = libc.fopen(str(tmp_path / "fk.txt").encode(), b"w")
+    assert L.fragkon_write_table(f, b"g.fa", b"a.bam", k, k5.ctypes.data, k3.ctypes.data) == 0
+    libc.fclose(f)
+    got5, got3 = tl.parse_fragkon_text((tmp_path / "fk.txt").read_text())
+    want5, want3 = np.minimum(k5, 0xFFFFFFFF).astype(np.uint32), np.minimum(k3, 0xFFFFFFFF).astype(np.uint32)
+    assert np.array_equal(got5, want5) and np.array_equal(got3, want3)
+    lines = (tmp_path / "fk.txt").read_text().splitlines()
+    assert lines[4 + 7] == "ACT\t4294967295\t0" and lines[4 + 9] == "AGC\t9\t4294967295"
+    f = libc.fopen(str(tmp_path / "gkc.txt").encode(), b"w")
+    assert L.gkc_write_table(f, k, k5.ctypes.data) == 0
+    libc.fclose(f)
+    rows = [ln.split("\t") for ln in (tmp_path / "gkc.txt").read_text().splitlines()]
+    assert [int(c) for _, c in rows] == [int(x) for x in want5]
+    assert rows[7] == ["ACT", "4294967295"] and rows[6] == ["ACG", "6"]
