@@ -118,8 +118,9 @@ struct pssbam_engine {
     // tuning overrides (environment, for experiments)
     int env_tile_reads = 0, env_grid_mult = 0, env_simple_blocks = 0, env_grid_wgs = 0, env_pieces = 0;
     bool warned_ablate = false;
-    uint32_t prep_lds[16] = {0};    // prep_kernel's memo, by kernel variant
-    int prep_occ[16] = {0};
+    uint32_t prep_lds[32] = {0};    // prep_kernel's memo, by kernel variant
+    int prep_occ[32] = {0};
+    bool use_compact = true;        // -r N <= 16: tally_compact (PSSBAM_COMPACT=0 keeps tally_tiled, for A/B runs)
     uint32_t *d_scratch = nullptr;  // per-workgroup partial tables of the tiled kernel
     size_t scratch_slots = 0;
     uint32_t dev_pieces = 0;       // prefix pieces sampled from a device-resident block
@@ -216,6 +217,7 @@ extern "C" int pssbam_engine_create(const pssbam_config *cfg, pssbam_engine **ou
     e->env_simple_blocks = env_int("PSSBAM_SIMPLE_BLOCKS");
     e->env_grid_wgs = env_int("PSSBAM_GRID_WGS");
     e->env_pieces = env_int("PSSBAM_PIECES");
+    if (getenv("PSSBAM_COMPACT")) e->use_compact = env_int("PSSBAM_COMPACT") != 0;
     *out = guard.release();
     return PSSBAM_OK;
 }
@@ -557,6 +559,31 @@ static int launch_tally(pssbam_engine *e, const uint8_t *d_recs, uint64_t nbytes
         }                                                                                          \
     } while (0)
         P.row_base = 0;
+        // -r N <= 16 (2 context rows + 16 positions): the short-window variant, one pass
+#define LAUNCH_COMPACT(KM, LK)                                                                             \
+    do {                                                                                           \
+        rc = prep_kernel(e, 16 | (KM ? 2 : 0) | (LK ? 1 : 0), tally_compact<KM, LK>, lds, &occ);   \
+        if (rc == PSSBAM_OK) {                                                                     \
+            uint32_t grid = (uint32_t)std::min<uint64_t>(n_tiles, (uint64_t)e->n_cu * occ * mult); \
+            if (e->env_grid_wgs > 0) grid = (uint32_t)std::min<uint64_t>(n_tiles, (uint64_t)e->env_grid_wgs); \
+            if (e->scratch_slots < grid) {                                                         \
+                HIP_TRY(hipStreamSynchronize(e->stream));                                          \
+                if (e->d_scratch) HIP_TRY(hipFree(e->d_scratch));                                  \
+                e->d_scratch = nullptr;                                                            \
+                e->scratch_slots = std::max<size_t>(grid, (size_t)e->n_cu * 8);                    \
+                HIP_TRY(hipMalloc(&e->d_scratch, e->scratch_slots * SCRATCH_WORDS * sizeof(uint32_t))); \
+            }                                                                                      \
+            P.scratch = e->d_scratch;                                                              \
+            hipLaunchKernelGGL((tally_compact<KM, LK>), dim3(grid), dim3(TILED_THREADS), lds, e->stream, P); \
+            hipLaunchKernelGGL(reduce_partials, dim3((SCRATCH_WORDS * REDUCE_GROUPS + 255) / 256), dim3(256), 0, e->stream, P, grid, \
+                               (uint32_t)(LK ? 1 : 0));                                            \
+        }                                                                                          \
+    } while (0)
+        if (do_pss && e->rows <= COMPACT_MAX_ROWS && e->use_compact && !e->has_rg) {
+            if (!do_kmer) LAUNCH_COMPACT(false, false);
+            else if (kmer_lds) LAUNCH_COMPACT(true, true);
+            else LAUNCH_COMPACT(true, false);
+        } else
         if (do_pss && do_kmer) { if (kmer_lds) LAUNCH_TILED(true, true, true, false); else LAUNCH_TILED(true, true, false, false); }
         else if (do_pss) LAUNCH_TILED(true, false, false, false);
         else { if (kmer_lds) LAUNCH_TILED(false, true, true, false); else LAUNCH_TILED(false, true, false, false); }
@@ -567,6 +594,7 @@ static int launch_tally(pssbam_engine *e, const uint8_t *d_recs, uint64_t nbytes
             LAUNCH_TILED(true, false, false, true);
         }
 #undef LAUNCH_TILED
+#undef LAUNCH_COMPACT
         if (rc != PSSBAM_OK) return rc;
     }
     HIP_TRY(hipGetLastError());

@@ -187,6 +187,41 @@ __device__ __forceinline__ RecHdr decode_hdr_lds(const LdsBytes &src, uint32_t r
     return h;
 }
 
+// The same in 32-bit arithmetic (tally_compact: the short-read kernel is VALU-bound).  l_seq above
+// 2^30 is declared malformed first -- a read of a gigabase is far outside the reference's own
+// 2047-character fields (precondition P2) -- so no sum below can wrap.
+__device__ __forceinline__ RecHdr decode_hdr_lds32(const LdsBytes &src, uint32_t rec_len) {
+    const uint32_t sh = src.off & 3u;
+    const uint32_t *q = (const uint32_t *)(src.base + (src.off & ~3u));
+    uint32_t r[10], w[9];
+#pragma unroll
+    for (int k = 0; k < 10; k++) r[k] = q[k];
+#pragma unroll
+    for (int k = 0; k < 9; k++) w[k] = __builtin_amdgcn_alignbyte(r[k + 1], r[k], sh);
+    RecHdr h;
+    h.rec_len = rec_len;
+    h.ref_id = (int32_t)w[1];
+    h.pos = (int32_t)w[2];
+    h.mapq = (w[3] >> 8) & 0xFFu;
+    h.n_cigar = w[4] & 0xFFFFu;
+    h.flag = w[4] >> 16;
+    h.l_seq = w[5];
+    h.tlen = (int32_t)w[8];
+    const uint32_t cig_off = 36u + (w[3] & 0xFFu);
+    const uint32_t seq_off = cig_off + 4u * h.n_cigar;
+    const uint32_t lq = min(h.l_seq, 1u << 30);
+    const uint32_t qual_off = seq_off + ((lq + 1u) >> 1);
+    const uint32_t aux_off = qual_off + lq;
+    h.well_formed = rec_len >= 36u && h.l_seq <= (1u << 30) && aux_off <= rec_len;
+    h.seq_off = h.well_formed ? seq_off : rec_len;
+    h.qual_off = h.well_formed ? qual_off : rec_len;
+    h.aux_off = h.well_formed ? aux_off : rec_len;
+    const uint32_t c0 = src.u32(h.well_formed ? cig_off : 0u);
+    h.cigar0 = (h.well_formed && h.n_cigar) ? c0 : 0u;
+    if (!h.well_formed) { h.n_cigar = 0; h.l_seq = 0; h.flag |= FL_UNMAP; h.ref_id = -1; }
+    return h;
+}
+
 // `samtools view -r RG`: keep the record iff it carries RG:Z:<rg>.  Walks the aux
 // fields (SAM spec 4.2.4); a field that runs past the record ends the walk.
 template <class Src>
@@ -305,14 +340,14 @@ struct RefsLdsCached {  // first `n_cached` entries (and the "*" entry, kept at 
     }
 };
 
-template <bool DO_PSS, bool DO_KMER, class Src, class Refs>
+template <bool DO_PSS, bool DO_KMER, bool MAY_HAVE_RG = true, class Src, class Refs>
 __device__ __forceinline__ Plan plan_head(const TallyParams &P, const Src &src, const RecHdr &h, const Refs &refs) {
     Plan pl;
     pl.pss_fwd = pl.pss_rev = false;
     pl.flag = h.flag;
 
     bool rg_drop = false;
-    if (P.rg) rg_drop = !has_read_group(src, h, P.rg, P.rg_len);  // uniform branch (kernel argument)
+    if (MAY_HAVE_RG && P.rg) rg_drop = !has_read_group(src, h, P.rg, P.rg_len);  // uniform branch (kernel argument)
 
     // line2saml: strlen(SEQ) vs strlen(QUAL)  (sam-parse.c:50)
     const uint32_t l_text = h.l_seq ? h.l_seq : 1u;

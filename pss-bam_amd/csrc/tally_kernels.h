@@ -599,6 +599,399 @@ __device__ __forceinline__ void tally_tiled_body(const TallyParams &P, const Tal
     if (tid < 16u) mine[SCRATCH_DELTA + tid] = tid < (uint32_t)ST_USED ? (uint32_t)lds_delta[tid] : 0u;
 }
 
+
+// ---------------------------------------------------------------------------------------
+// tally_compact: the tiled kernel for -r N <= 16 (the tool's default is 15)
+// ---------------------------------------------------------------------------------------
+// Short windows leave half of tally_tiled's work on dead positions: its 32-byte windows cost
+// four v_perm groups per end and one COLUMNS wave-iteration per read whatever N is, and short
+// records (30-80 bp ancient-DNA reads, 138 B) no longer hide that behind their record stream:
+// BASELINE config 4 ran at 17 VALU wave-instructions per read, 66 % VALU-busy, HBM half idle
+// (profiles/r02_C4_before.json).  This variant keeps the pipeline (LDS-DMA staged prefixes ->
+// lane pair per read -> code sheet -> column tally) and changes the window geometry:
+//   * a window holds the 16 POSITIONS of an end only (two v_perm groups): left end = read bases
+//     0..15 / reference s..s+15, right end = read bases L-16..L-1 / reference s+L-16..s+L-1
+//     (position i from the right = byte 15-i), so both ends use the same two groups and the left
+//     end's nibble stream is always even-aligned;
+//   * one dwordx4 gather per end fetches its 16 positions AND its two context bases (18 nibbles
+//     at any nibble alignment fit 4 dwords);
+//   * the context rows (0, 1) can only take the four diagonal cells: each (read, end) lane adds
+//     them with two LDS atomics into a 16-fold replicated 16-word table (lane & 15 picks the
+//     replica, so the AA/CC/GG/TT skew meets at most 4 lanes per word);
+//   * the code sheet row is 32 bytes, and COLUMNS takes TWO reads per wave-iteration:
+//     lane = (read parity, end, byte); the count table's 32 slots per code are (end, position),
+//     so the 32 lanes of a half-wave still never share a word or a bank; the two ends' slots are
+//     summed when the table leaves LDS.
+// The DMA issue loop addresses through an SGPR base + 32-bit lane offset (no 64-bit VALU adds)
+// and saves/restores m0 around the instruction (the compiler does not model the write).
+constexpr uint32_t COMPACT_MAX_ROWS = 18;     // 2 context rows + 16 positions
+constexpr uint32_t CTX_REP = 16;              // replicas of the context-row cells
+constexpr uint32_t CTX_WORDS = 16 * CTX_REP;  // [table 2][row 2][base 4][replica 16]
+
+// piece q of the tile -> stage + q*16, source = record's 16-byte aligned start + 16 * piece;
+// `full` tiles (count == T, every piece inside the block) skip the per-lane bounds tests
+__device__ __forceinline__ void stage_tile_dma32(const uint8_t *recs, uint32_t recs_limit32, const uint32_t *tile_offs,
+                                                 uint32_t count, uint32_t pieces, uint8_t *stage, uint32_t tid) {
+    const uint32_t n_pieces = count * pieces;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)stage;
+    const uint32_t magic = ((1u << 20) + pieces - 1u) / pieces;   // q / pieces, exact for q < 2^13, pieces <= 64
+    for (uint32_t q0 = (tid & ~63u); q0 < n_pieces; q0 += TILED_THREADS) {
+        const uint32_t q = q0 + (tid & 63u);
+        const uint32_t jq = (q * magic) >> 20;
+        const uint32_t j = min(jq, count - 1u), pc = q - jq * pieces;
+        const uint32_t a = (tile_offs[j] & ~15u) + 16u * pc;     // < 4 GiB: the block is
+        if (q < n_pieces && a <= recs_limit32) {                  // recs_limit32 = readable end - 16
+            const uint32_t m0v = __builtin_amdgcn_readfirstlane(lds0 + (q0 << 4));
+            uint32_t keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(a), "s"(recs), "s"(m0v) : "memory");
+        }
+    }
+}
+
+struct LdsTableCompact {  // overflow records (one lane, global-memory decode) in the compact layout
+    uint32_t *t;          // [(cell << 1) | table][32 slots]: slot = end * 16 + (row - 2); both ends are summed at the end
+    uint32_t *ctx;        // [table][row][base][replica]
+    __device__ __forceinline__ void add(uint32_t table, uint32_t row, uint32_t cell) const {
+        if (row >= 2u) { if (row < COMPACT_MAX_ROWS) atomicAdd(&t[(((cell << 1) | table) << 5) + (row - 2u)], 1u); }
+        else atomicAdd(&ctx[((table * 2u + row) * 4u + cell / 5u) * CTX_REP], 1u);   // context cells are diagonal: 0,5,10,15
+    }
+};
+
+template <bool DO_KMER, bool LDS_KMER>
+__device__ __attribute__((noinline)) uint32_t tally_overflow_record_compact(const TallyParams *kernarg, uint32_t o0, uint32_t o1,
+                                                                            uint32_t *table, uint32_t *ctx, uint32_t *lds_kmer) {
+    const TallyParams &P = *kernarg;
+    GlobalBytes gsrc{P.recs + o0};
+    const RecHdr gh = decode_hdr(gsrc, o1 - o0);
+    const Plan gpl = make_plan<true, DO_KMER>(P, gsrc, gh);
+    if (gpl.pss_fwd || gpl.pss_rev) tally_pss_record(P, LdsTableCompact{table, ctx}, gsrc, gh, gpl);
+    bool kfail = false;
+    if (DO_KMER && (gpl.fk5 || gpl.fk3)) kfail = tally_kmer_record<LDS_KMER>(P, gpl, lds_kmer);
+    return record_events(true, DO_KMER, gpl, kfail);
+}
+
+template <bool DO_KMER, bool LDS_KMER>
+__device__ __forceinline__ void tally_compact_body(const TallyParams &P, const TallyParams *kernarg,
+                                                   uint8_t *__restrict__ stage, uint8_t *__restrict__ sheet,
+                                                   uint32_t *__restrict__ table, uint32_t *__restrict__ toffs,
+                                                   uint32_t *__restrict__ lds_kmer, int32_t *__restrict__ lds_delta,
+                                                   uint4 *__restrict__ refs_lds, uint32_t *__restrict__ ctx_rep,
+                                                   uint32_t *__restrict__ ovf_list, uint32_t *__restrict__ ovf_n) {
+    const uint32_t T = P.reads_per_tile;
+    const uint32_t pieces = P.prefix_pieces;
+    const uint32_t recs_limit32 = (uint32_t)(((P.recs_bytes + 15ull) & ~15ull) - 16ull);  // last piece start that is readable
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
+
+    // -U / -D membership by packed-reference nibble, complemented form in the upper half:
+    // bit n = nibble n passes, bit 16 + n = the complement of nibble n passes
+    uint32_t up_tab = 0u, dn_tab = 0u;
+#pragma unroll
+    for (uint32_t n = 0; n < 8u; n++) {
+        const uint32_t c = n < 4u ? 3u - n : n;
+        const uint32_t u = n < 4u ? (P.acgt_ctx >> (2u * n)) & 1u : n & 1u, uc = c < 4u ? (P.acgt_ctx >> (2u * c)) & 1u : c & 1u;
+        const uint32_t d = n < 4u ? (P.acgt_ctx >> (2u * n + 1u)) & 1u : (n >> 1) & 1u, dc = c < 4u ? (P.acgt_ctx >> (2u * c + 1u)) & 1u : (c >> 1) & 1u;
+        up_tab |= (u << n) | (uc << (16u + n));
+        dn_tab |= (d << n) | (dc << (16u + n));
+    }
+
+    for (uint32_t i = tid; i < TABLE_WORDS; i += TILED_THREADS) table[i] = 0u;
+    if (tid < CTX_WORDS) ctx_rep[tid] = 0u;
+    if (LDS_KMER)
+        for (uint32_t i = tid; i < 2u * (1u << (2 * P.K)); i += TILED_THREADS) lds_kmer[i] = 0u;
+    if (tid < ST_USED) lds_delta[tid] = 0;
+    if (tid == 0u) *ovf_n = 0u;
+    const uint32_t n_ref_cached = min((uint32_t)P.n_ref, REF_LDS_ENTRIES);
+    if (tid < n_ref_cached) refs_lds[tid] = P.ref_info[tid];
+    if (tid == n_ref_cached) refs_lds[tid] = P.ref_info[P.n_ref];
+    const uint32_t all_tiles = (P.n_recs + T - 1u) / T;
+    uint32_t tile = blockIdx.x;
+    const uint32_t tstride = gridDim.x, n_tiles = all_tiles;
+    uint32_t off_a = 0;
+    const uint32_t TOFF = TILED_MAX_T + 4u;
+    auto load_offsets = [&](uint32_t t) {
+        const uint32_t r0 = t * T;
+        if (tid <= T && r0 + tid <= P.n_recs) off_a = P.offs[r0 + tid];
+    };
+    auto tile_count = [&](uint32_t t) { return min(T, P.n_recs - t * T); };
+    __syncthreads();
+    if (tile < n_tiles) {
+        load_offsets(tile);
+        if (tid <= T) toffs[tid] = off_a;
+        __syncthreads();
+        stage_tile_dma32(P.recs, recs_limit32, toffs, tile_count(tile), pieces, stage, tid);
+        if (tile + tstride < n_tiles) load_offsets(tile + tstride);
+    }
+
+    for (uint32_t it = 0; tile < n_tiles; tile += tstride, it++) {
+        const uint32_t par = it & 1u;
+        const uint32_t *cur_offs = toffs + par * TOFF;
+        const uint32_t r0 = tile * T;
+        const uint32_t count = min(T, P.n_recs - r0);
+        const uint32_t next = tile + tstride;
+
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (next < n_tiles && tid <= T) toffs[(par ^ 1u) * TOFF + tid] = off_a;
+        __syncthreads();
+
+        // ---- CODES, part A: everything that reads `stage` --------------------------------------
+        const uint32_t j = tid >> 1, e = tid & 1u;
+        const bool lane_on = tid < 2u * T;
+        const bool in_tile = lane_on && j < count;
+        uint32_t o0 = 0, o1 = 0;
+        if (in_tile) { o0 = cur_offs[j]; o1 = cur_offs[j + 1]; }
+        const uint32_t avail = pieces * 16u - (o0 & 15u);
+        const bool hdr_ok = in_tile && o1 - o0 >= 36u && avail >= 48u;
+        LdsBytes src{stage, hdr_ok ? j * pieces * 16u + (o0 & 15u) : 0u};
+        const RecHdr h = decode_hdr_lds32(src, hdr_ok ? o1 - o0 : 0u);
+        const uint32_t needed = h.qual_off + 1u;   // (the -R filter, which walks the aux fields, stays with tally_tiled)
+        const bool in_stage = hdr_ok && needed <= avail;
+        Plan pl = plan_head<true, DO_KMER, false>(P, src, h, RefsLdsCached{refs_lds, P.ref_info, n_ref_cached, (uint32_t)P.n_ref});
+        if (!in_stage) { pl.status = RS_LIVE; pl.live = pl.pss_cand = pl.fk5 = pl.fk3 = false; }
+        const bool cand = pl.pss_cand;
+        // this end's 16 positions + 2 context bases: 18 nibbles of the packed reference from
+        //   left : s-2 .. s+15      (nibbles 0,1 = second, first context base; 2..17 = positions 0..15)
+        //   right: s+L-16 .. s+L+1  (nibbles 0..15 = positions, byte w <-> position 15-w from the
+        //                            right end; 16, 17 = first, second context base)
+        uint32_t gq[4] = {0u, 0u, 0u, 0u};
+        uint32_t gsh = 0u;
+        if (cand) {
+            const uint64_t ga = pl.gbase + (uint64_t)(int64_t)((int32_t)pl.s + (e ? (int32_t)pl.L - 16 : -2));
+            const Quad q0 = *(const Quad *)(P.genome4 + (ga >> 3));
+#pragma unroll
+            for (int k = 0; k < 4; k++) gq[k] = q0.v[k];
+            gsh = 4u * (uint32_t)(ga & 7ull);
+        }
+        // read bases as a nibble stream aligned with the window bytes: stream nibble b <-> read base
+        // n0 + b, n0 = 0 (left) or L-16 (right; may be negative for L < 16: those positions are
+        // beyond N <= L and never tallied).  9 bytes at any byte alignment = three aligned dwords.
+        const int32_t n0 = e ? (int32_t)pl.L - 16 : 0;
+        uint32_t rr[3] = {0u, 0u, 0u};
+        uint32_t ssh = 0u;
+        if (cand) {
+            const int32_t n0a = min(n0, (int32_t)h.l_seq);
+            const uint32_t sa = src.off + (uint32_t)((int32_t)h.seq_off + (n0a >> 1));
+            const uint32_t *qs = (const uint32_t *)(stage + (sa & ~3u));
+            ssh = sa & 3u;
+#pragma unroll
+            for (int k = 0; k < 3; k++) rr[k] = qs[k];
+        }
+        const uint32_t kwhich = e ^ (pl.rev ? 1u : 0u);
+        const bool kmer_try = DO_KMER && (kwhich ? pl.fk3 : pl.fk5);
+        uint32_t kw[3] = {0u, 0u, 0u};
+        uint32_t ksh = 0u;
+        if (kmer_try) {
+            int64_t w5, w3;
+            kmer_windows(pl, P.K, w5, w3);
+            const uint64_t ka = pl.gbase + (uint64_t)(kwhich ? w3 : w5);
+            const Tri kq = *(const Tri *)(P.genome4 + (ka >> 3));
+#pragma unroll
+            for (int k = 0; k < 3; k++) kw[k] = kq.v[k];
+            ksh = 4u * (uint32_t)(ka & 7ull);
+        }
+        // a record whose needed prefix is not staged is queued and handled after COLUMNS, where
+        // almost nothing is live (the out-of-line call would otherwise sit in the register-hungry
+        // middle of the tile)
+        if (in_tile && !in_stage && e == 0u) ovf_list[atomicAdd(ovf_n, 1u)] = j;
+        // consume the gathered registers before the next DMA is issued (vmcnt retires in order)
+        uint32_t A[3];  // nibble q of A[m] = window nibble 8m + q
+#pragma unroll
+        for (int m = 0; m < 3; m++) A[m] = __builtin_amdgcn_alignbit(gq[m + 1], gq[m], gsh);
+#pragma unroll
+        for (int k = 0; k < 2; k++) kw[k] = __builtin_amdgcn_alignbit(kw[k + 1], kw[k], ksh);
+#pragma unroll
+        for (int m = 0; m < 3; m++) asm volatile("" : "+v"(A[m]));
+        if (DO_KMER) {
+#pragma unroll
+            for (int k = 0; k < 2; k++) asm volatile("" : "+v"(kw[k]));
+        }
+        __syncthreads();
+
+        if (next < n_tiles) {
+            stage_tile_dma32(P.recs, recs_limit32, toffs + (par ^ 1u) * TOFF, tile_count(next), pieces, stage, tid);
+            if (next + tstride < n_tiles) load_offsets(next + tstride);
+        }
+
+        // ---- CODES, part B: registers only -----------------------------------------------------
+        {
+            // context nibbles: left = nibbles 0 (second), 1 (first) of A[0]; right = nibbles 0 (first), 1 (second) of A[2]
+            const uint32_t cx = e ? A[2] : A[0];
+            const uint32_t c_lo = cx & 15u, c_hi = (cx >> 4) & 15u;
+            const uint32_t own1 = e ? c_lo : c_hi, own2 = e ? c_hi : c_lo;   // first / second context base of this end
+            const uint32_t other1 = (uint32_t)__shfl_xor((int)own1, 1);
+            {   // pss-bam.c:134-142, :428-494 with the membership tables
+                const uint32_t left1 = e ? other1 : own1, right1 = e ? own1 : other1;
+                const uint32_t rsh = pl.rev ? 16u : 0u;
+                const bool up_ok = ((up_tab >> ((pl.rev ? right1 : left1) + rsh)) & 1u) != 0;
+                const bool dn_ok = ((dn_tab >> ((pl.rev ? left1 : right1) + rsh)) & 1u) != 0;
+                const bool paired = (pl.flag & FL_PAIRED) != 0;
+                const bool r1 = (pl.flag & FL_READ1) != 0, r2 = (pl.flag & FL_READ2) != 0;
+                pl.pss_fwd = pl.pss_cand && (paired ? (r1 && up_ok) : (up_ok && dn_ok));
+                pl.pss_rev = pl.pss_cand && (paired ? (!(r1 && up_ok) && r2 && dn_ok) : (up_ok && dn_ok));
+            }
+            // the 16 position nibbles: left = window nibbles 2..17, right = 0..15
+            const uint32_t G0 = e ? A[0] : __builtin_amdgcn_alignbit(A[1], A[0], 8);
+            const uint32_t G1 = e ? A[1] : __builtin_amdgcn_alignbit(A[2], A[1], 8);
+            uint32_t code_w[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) code_w[k] = CODE_NONE * 0x01010101u;
+            const uint32_t tsel = e ^ (pl.rev ? 1u : 0u);
+            const bool tallied = cand && (tsel ? pl.pss_rev : pl.pss_fwd);
+            if (tallied) {
+                // (same v_perm byte tables as tally_tiled, two groups)
+                uint32_t S[3];
+                S[0] = __builtin_amdgcn_alignbyte(rr[1], rr[0], ssh);
+                S[1] = __builtin_amdgcn_alignbyte(rr[2], rr[1], ssh);
+                S[2] = __builtin_amdgcn_alignbyte(0u, rr[2], ssh);
+                const bool odd = (n0 & 1) != 0;
+                const uint32_t M = 0x0F0F0F0Fu;
+                const uint32_t sx = pl.rev ? 0u : 0x1E1E1E1Eu;
+                const uint32_t tsel4 = tsel * 0x01010101u;
+                const uint32_t Gw[2] = {G0, G1};
+                uint32_t RE[2], RO[2], GE[2], GO[2];
+#pragma unroll
+                for (int m = 0; m < 2; m++) {
+                    const uint32_t S1 = __builtin_amdgcn_alignbyte(S[m + 1], S[m], 1);
+                    const uint32_t Ax = odd ? S1 : S[m];
+                    const uint32_t hiA = (Ax >> 4) & M, loS = S[m] & M;
+                    const uint32_t E = odd ? loS : hiA, O = odd ? hiA : loS;
+                    RE[m] = __builtin_amdgcn_perm(0xFF1098FFu, 0xFFFFFF08u, E ^ 0x04040404u);
+                    RO[m] = __builtin_amdgcn_perm(0xFF1098FFu, 0xFFFFFF08u, O ^ 0x04040404u);
+                    GE[m] = __builtin_amdgcn_perm(0xFFFFFFFFu, 0x00020406u, Gw[m] & M);
+                    GO[m] = __builtin_amdgcn_perm(0xFFFFFFFFu, 0x00020406u, (Gw[m] >> 4) & M);
+                }
+                // bases at or beyond l_seq do not exist (precondition P3): blank them
+                const int32_t have_s = (int32_t)h.l_seq - n0;
+                const uint32_t have = have_s <= 0 ? 0u : have_s >= 16 ? 16u : (uint32_t)have_s;
+                if (__any(have < 16u)) {
+#pragma unroll
+                    for (int m = 0; m < 2; m++) {
+                        const uint32_t left = have > 8u * m ? have - 8u * m : 0u;
+                        const uint32_t ne = min((left + 1u) >> 1, 4u), no = min(left >> 1, 4u);
+                        RE[m] |= ne >= 4u ? 0u : ~((1u << (8u * ne)) - 1u);
+                        RO[m] |= no >= 4u ? 0u : ~((1u << (8u * no)) - 1u);
+                    }
+                }
+#pragma unroll
+                for (int m = 0; m < 2; m++) {
+                    code_w[2 * m] = ((RE[m] | GE[m] | tsel4) ^ sx) & 0x3F3F3F3Fu;
+                    code_w[2 * m + 1] = ((RO[m] | GO[m] | tsel4) ^ sx) & 0x3F3F3F3Fu;
+                }
+                // context rows (pss-bam.c:169-189): row 1 <- first context base, row 0 <- second; the
+                // cell is the diagonal one of the base (complemented for reverse-strand reads)
+                const uint32_t rep = lane & (CTX_REP - 1u);
+                const uint32_t b1 = pl.rev ? 3u - own1 : own1, b2 = pl.rev ? 3u - own2 : own2;
+                if (own1 < 4u) atomicAdd(&ctx_rep[((tsel * 2u + 1u) * 4u + b1) * CTX_REP + rep], 1u);
+                if (own2 < 4u) atomicAdd(&ctx_rep[((tsel * 2u + 0u) * 4u + b2) * CTX_REP + rep], 1u);
+            }
+            bool kmer_ok = true;
+            if (kmer_try) {
+                uint32_t bin = 0u, bad = 0u;
+#pragma unroll
+                for (int t = 0; t < 12; t++) {
+                    if (t < P.K) {
+                        const uint32_t c = (kw[t >> 3] >> (4 * (t & 7))) & 0xFu;
+                        bad |= c & ~3u;
+                        bin = pl.rev ? (bin | ((3u - (c & 3u)) << (2 * t))) : ((bin << 2) | (c & 3u));
+                    }
+                }
+                kmer_ok = bad == 0u;
+                if (kmer_ok) {
+                    if (LDS_KMER) atomicAdd(&lds_kmer[(kwhich ? (1u << (2 * P.K)) : 0u) + bin], 1u);
+                    else atomicAdd(&P.counters[(kwhich ? P.off_k3 : P.off_k5) + bin], 1ull);
+                }
+            }
+            if (lane_on)   // code sheet row of read j: 16 bytes per end, [E0 O0 E1 O1]
+                *(uint4 *)(sheet + j * 32u + e * 16u) = make_uint4(code_w[0], code_w[1], code_w[2], code_w[3]);
+            bool kfail = false;
+            if (DO_KMER) {
+                const int bad = (kmer_try && !kmer_ok) ? 1 : 0;
+                const int bad_other = __shfl_xor(bad, 1);
+                kfail = (bad | bad_other) != 0;
+            }
+            if (e == 0u && in_stage) book_events(true, DO_KMER, record_events(true, DO_KMER, pl, kfail), lds_delta);
+        }
+        __syncthreads();
+
+        // ---- COLUMNS: two reads per wave-iteration, lane = (read parity, end, sheet byte) ----------
+        {
+            // sheet byte b of an end holds window byte w = 8*(b/8) + 2*(b%4) + (b/4)%2; left: position w,
+            // right: position 15-w; table slot = end*16 + position
+            const uint32_t ee = (lane >> 4) & 1u, b = lane & 15u;
+            const uint32_t w = (b & 8u) + 2u * (b & 3u) + ((b >> 2) & 1u);
+            const uint32_t posn = ee ? 15u - w : w;
+            const uint32_t slot = ee * 16u + posn;
+            const uint32_t per_wave = (((count + TILED_WAVES - 1u) / TILED_WAVES) + 1u) & ~1u;   // even: pairs stay in one wave
+            const uint32_t j0 = min(count, wave * per_wave), j1 = min(count, j0 + per_wave);
+            if (posn < (uint32_t)P.N) {
+                const uint32_t rd = lane >> 5;   // which read of the pair
+                uint32_t jj = j0;
+                for (; jj + 16u <= j1; jj += 16u) {
+                    uint32_t c[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) c[u] = sheet[(jj + 2u * u) * 32u + lane];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) atomicAdd(&table[(c[u] << 5) + slot], 1u);
+                }
+                for (; jj < j1; jj += 2u)
+                    if (jj + rd < j1) atomicAdd(&table[((uint32_t)sheet[jj * 32u + lane] << 5) + slot], 1u);
+            }
+        }
+        // queued overflow records of this tile (rare: a record of tens of KB, or a block whose later
+        // records are longer than the sampled prefix).  ovf_n was final at the barrier before COLUMNS.
+        const uint32_t n_ovf = *ovf_n;
+        if (n_ovf) {
+            for (uint32_t i = tid; i < n_ovf; i += TILED_THREADS) {
+                const uint32_t jo = ovf_list[i];
+                const uint32_t ev = tally_overflow_record_compact<DO_KMER, LDS_KMER>(kernarg, cur_offs[jo], cur_offs[jo + 1u], table,
+                                                                                    ctx_rep, lds_kmer);
+                book_events(true, DO_KMER, ev, lds_delta);
+                atomicAdd(&lds_delta[ST_SLOW_PATH], 1);
+            }
+            __syncthreads();   // everyone has read n_ovf / the list
+            if (tid == 0u) *ovf_n = 0u;
+        }
+    }
+
+    __syncthreads();
+    // scratch slot in tally_tiled's format ([code][row]): rows 2.. = both ends' slots summed,
+    // rows 0,1 = the context replicas summed (diagonal cells only)
+    uint32_t *mine = P.scratch + (size_t)blockIdx.x * SCRATCH_WORDS;
+    for (uint32_t i = tid; i < 32u * 32u; i += TILED_THREADS) {
+        const uint32_t ct = i >> 5, row = i & 31u;
+        uint32_t v = 0u;
+        if (row >= 2u && row < COMPACT_MAX_ROWS) v = table[(ct << 5) + (row - 2u)] + table[(ct << 5) + 16u + (row - 2u)];
+        else if (row < 2u) {
+            const uint32_t t = ct & 1u, cell = ct >> 1;
+            if (cell % 5u == 0u) {
+                const uint32_t *rp = ctx_rep + ((t * 2u + row) * 4u + cell / 5u) * CTX_REP;
+                for (uint32_t k = 0; k < CTX_REP; k++) v += rp[k];
+            }
+        }
+        mine[i] = v;
+    }
+    for (uint32_t i = tid; i < 512u; i += TILED_THREADS)
+        mine[SCRATCH_KMER + i] = (LDS_KMER && i < 2u * (1u << (2 * P.K))) ? lds_kmer[i] : 0u;
+    if (tid < 16u) mine[SCRATCH_DELTA + tid] = tid < (uint32_t)ST_USED ? (uint32_t)lds_delta[tid] : 0u;
+}
+
+template <bool DO_KMER, bool LDS_KMER>
+__global__ void __launch_bounds__(TILED_THREADS) tally_compact(const TallyParams P) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t stage[];
+    __shared__ __attribute__((aligned(16))) uint8_t sheet[TILED_MAX_T * 32u];
+    __shared__ uint32_t table[TABLE_WORDS];
+    __shared__ uint32_t toffs[2u * (TILED_MAX_T + 4u)];
+    __shared__ uint32_t lds_kmer[LDS_KMER ? 2u * (1u << (2 * KMER_LDS_MAX_K)) : 1u];
+    __shared__ int32_t lds_delta[ST_USED];
+    __shared__ uint4 refs_lds[REF_LDS_ENTRIES + 1];
+    __shared__ uint32_t ctx_rep[CTX_WORDS];
+    __shared__ uint32_t ovf_list[TILED_MAX_T + 1];   // [TILED_MAX_T] = fill count
+    const TallyParams *kernarg = (const TallyParams *)__builtin_amdgcn_kernarg_segment_ptr();
+    tally_compact_body<DO_KMER, LDS_KMER>(P, kernarg, stage, sheet, table, toffs, lds_kmer, lds_delta, refs_lds, ctx_rep, ovf_list,
+                                          ovf_list + TILED_MAX_T);
+}
+
 // Sums the per-workgroup partials of one tally_tiled launch into the u64 counter block.
 // Thread (word w, group g) adds up slots g, g+REDUCE_GROUPS, ... of word w (loads coalesce across
 // w) and contributes one atomic; launched on the same stream right behind the tally kernel.
