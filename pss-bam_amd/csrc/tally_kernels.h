@@ -627,6 +627,7 @@ __device__ __forceinline__ void tally_tiled_body(const TallyParams &P, const Tal
 constexpr uint32_t COMPACT_MAX_ROWS = 18;     // 2 context rows + 16 positions
 constexpr uint32_t CTX_REP = 16;              // replicas of the context-row cells
 constexpr uint32_t CTX_WORDS = 16 * CTX_REP;  // [table 2][row 2][base 4][replica 16]
+constexpr uint32_t COMPACT_TABLE_WORDS = 33 * 32;  // codes 0..31 + one trash row (5 workgroups per CU instead of 4)
 
 // piece q of the tile -> stage + q*16, source = record's 16-byte aligned start + 16 * piece;
 // `full` tiles (count == T, every piece inside the block) skip the per-lane bounds tests
@@ -696,7 +697,7 @@ __device__ __forceinline__ void tally_compact_body(const TallyParams &P, const T
         dn_tab |= (d << n) | (dc << (16u + n));
     }
 
-    for (uint32_t i = tid; i < TABLE_WORDS; i += TILED_THREADS) table[i] = 0u;
+    for (uint32_t i = tid; i < COMPACT_TABLE_WORDS; i += TILED_THREADS) table[i] = 0u;
     if (tid < CTX_WORDS) ctx_rep[tid] = 0u;
     if (LDS_KMER)
         for (uint32_t i = tid; i < 2u * (1u << (2 * P.K)); i += TILED_THREADS) lds_kmer[i] = 0u;
@@ -912,18 +913,19 @@ __device__ __forceinline__ void tally_compact_body(const TallyParams &P, const T
             }
             if (e == 0u && in_stage) book_events(true, DO_KMER, record_events(true, DO_KMER, pl, kfail), lds_delta);
         }
-        __syncthreads();
+        // (no barrier here: wave w wrote the sheet rows of reads 32w .. 32w+31 -- j = tid >> 1 -- and
+        //  its COLUMNS pass reads exactly those rows)
 
         // ---- COLUMNS: two reads per wave-iteration, lane = (read parity, end, sheet byte) ----------
         {
             // sheet byte b of an end holds window byte w = 8*(b/8) + 2*(b%4) + (b/4)%2; left: position w,
-            // right: position 15-w; table slot = end*16 + position
+            // right: position 15-w; table slot = end*16 + position.  Every code >= 32 ("no count")
+            // lands in the one trash row 32.
             const uint32_t ee = (lane >> 4) & 1u, b = lane & 15u;
             const uint32_t w = (b & 8u) + 2u * (b & 3u) + ((b >> 2) & 1u);
             const uint32_t posn = ee ? 15u - w : w;
             const uint32_t slot = ee * 16u + posn;
-            const uint32_t per_wave = (((count + TILED_WAVES - 1u) / TILED_WAVES) + 1u) & ~1u;   // even: pairs stay in one wave
-            const uint32_t j0 = min(count, wave * per_wave), j1 = min(count, j0 + per_wave);
+            const uint32_t j0 = min(count, wave * 32u), j1 = min(count, j0 + 32u);
             if (posn < (uint32_t)P.N) {
                 const uint32_t rd = lane >> 5;   // which read of the pair
                 uint32_t jj = j0;
@@ -932,14 +934,14 @@ __device__ __forceinline__ void tally_compact_body(const TallyParams &P, const T
 #pragma unroll
                     for (int u = 0; u < 8; u++) c[u] = sheet[(jj + 2u * u) * 32u + lane];
 #pragma unroll
-                    for (int u = 0; u < 8; u++) atomicAdd(&table[(c[u] << 5) + slot], 1u);
+                    for (int u = 0; u < 8; u++) atomicAdd(&table[(min(c[u], 32u) << 5) + slot], 1u);
                 }
                 for (; jj < j1; jj += 2u)
-                    if (jj + rd < j1) atomicAdd(&table[((uint32_t)sheet[jj * 32u + lane] << 5) + slot], 1u);
+                    if (jj + rd < j1) atomicAdd(&table[(min((uint32_t)sheet[jj * 32u + lane], 32u) << 5) + slot], 1u);
             }
         }
         // queued overflow records of this tile (rare: a record of tens of KB, or a block whose later
-        // records are longer than the sampled prefix).  ovf_n was final at the barrier before COLUMNS.
+        // records are longer than the sampled prefix).  ovf_n was final at the barrier behind CODES-A.
         const uint32_t n_ovf = *ovf_n;
         if (n_ovf) {
             for (uint32_t i = tid; i < n_ovf; i += TILED_THREADS) {
@@ -980,7 +982,7 @@ template <bool DO_KMER, bool LDS_KMER>
 __global__ void __launch_bounds__(TILED_THREADS) tally_compact(const TallyParams P) {
     extern __shared__ __attribute__((aligned(16))) uint8_t stage[];
     __shared__ __attribute__((aligned(16))) uint8_t sheet[TILED_MAX_T * 32u];
-    __shared__ uint32_t table[TABLE_WORDS];
+    __shared__ uint32_t table[COMPACT_TABLE_WORDS];
     __shared__ uint32_t toffs[2u * (TILED_MAX_T + 4u)];
     __shared__ uint32_t lds_kmer[LDS_KMER ? 2u * (1u << (2 * KMER_LDS_MAX_K)) : 1u];
     __shared__ int32_t lds_delta[ST_USED];

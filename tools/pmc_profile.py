@@ -80,7 +80,7 @@ for name, flags in PASSES:
                 cnt[(k, row["Counter_Name"])] += 1
             rec["counters"] = {}
             for k, v in acc.items():
-                if "tally_tiled" in k or "tally_simple" in k:
+                if "tally_tiled" in k or "tally_simple" in k or "tally_compact" in k:
                     rec["counters"][k[:90]] = {c: {"per_dispatch": val / cnt[(k, c)], "dispatches": cnt[(k, c)]}
                                                for c, val in v.items()}
     summary["passes"][name] = rec
