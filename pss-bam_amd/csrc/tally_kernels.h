@@ -230,9 +230,9 @@ __device__ __forceinline__ void stage_tile_dma(const uint8_t *recs, uint64_t rec
         if (q < n_pieces && a + 16u <= recs_limit) {
             const uint8_t *src = recs + a;
             const uint32_t m0v = __builtin_amdgcn_readfirstlane(lds0 + (q0 << 4));
-            asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(m0v) : "memory");
-            // (m0 is written: gfx950 DS instructions do not read it and hipcc keeps nothing live in
-            //  it in this kernel -- checked in the ISA; naming it as a clobber is rejected as reserved)
+            uint32_t keep;   // m0 is compiler-reserved and cannot be named as a clobber: save and restore it
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(src), "s"(m0v) : "memory");
         }
     }
 }
@@ -563,7 +563,8 @@ __device__ __forceinline__ void tally_tiled_body(const TallyParams &P, const Tal
             }
             if (e == 0u && pass0) book_events(DO_PSS, DO_KMER, in_stage ? record_events(DO_PSS, DO_KMER, pl, kfail) : ev_over, lds_delta);
         }
-        __syncthreads();
+        // (no barrier: wave w wrote the sheet rows of reads 32w .. 32w+31 -- j = tid >> 1 -- and its
+        //  COLUMNS pass below reads exactly those rows)
 
         // ---- COLUMNS: wave-per-read, lane = (end, window byte) -----------------------------------
         if (DO_PSS && !(ablate & 1u)) {
@@ -571,8 +572,7 @@ __device__ __forceinline__ void tally_tiled_body(const TallyParams &P, const Tal
             const uint32_t e = lane >> 5, b = lane & 31u;
             const uint32_t wpos = (b & 24u) + 2u * (b & 3u) + ((b >> 2) & 1u);
             const uint32_t row = e ? 31u - wpos : wpos;
-            const uint32_t per_wave = (count + TILED_WAVES - 1u) / TILED_WAVES;
-            const uint32_t j0 = wave * per_wave, j1 = min(count, j0 + per_wave);
+            const uint32_t j0 = min(count, wave * 32u), j1 = min(count, j0 + 32u);
             if (row < n_live) {  // (lanes of dead rows would only ever see CODE_NONE)
                 uint32_t j = j0;
                 for (; j + 8u <= j1; j += 8u) {
