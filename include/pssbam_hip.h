@@ -139,6 +139,17 @@ int pssbam_engine_set_references(pssbam_engine *e, int32_t n_ref, const char *co
 int pssbam_engine_submit(pssbam_engine *e, const void *records, uint64_t nbytes,
                          const uint32_t *offsets, uint32_t n_records);
 
+/* The same without the wait: returns as soon as the copy and the kernel are enqueued, so that one
+ * host thread can keep the PCIe links of several GPUs busy at once (one engine per GPU).  The
+ * caller's buffers must stay untouched until pssbam_engine_wait_copied(e, *ticket) has returned
+ * (or pssbam_engine_copy_done says 1, or the engine has been synced).  *ticket == 0: nothing was
+ * in flight (empty block).  Replaces nothing in the reference (its loop is synchronous,
+ * pss-bam.c:764-783); pssbam_engine_submit == submit_async + wait_copied. */
+int pssbam_engine_submit_async(pssbam_engine *e, const void *records, uint64_t nbytes,
+                               const uint32_t *offsets, uint32_t n_records, uint64_t *ticket);
+int pssbam_engine_wait_copied(pssbam_engine *e, uint64_t ticket);
+int pssbam_engine_copy_done(pssbam_engine *e, uint64_t ticket);   /* 1 done, 0 in flight, < 0 error */
+
 /* Same with both arrays already resident in device memory; nothing is copied and the
  * buffers must stay valid until pssbam_engine_sync / finish.  d_records must be 16-byte
  * aligned and readable up to nbytes rounded up to 16 (any hipMalloc / torch allocation is). */
@@ -190,6 +201,11 @@ int pssbam_engine_timer_end(pssbam_engine *e, float *ms);
 /* Sum of the tally kernels' own durations (event pair around every launch) and their
  * number since the last call with reset != 0. */
 int pssbam_engine_kernel_time(pssbam_engine *e, double *total_ms, uint64_t *n_launches, int reset);
+
+/* Drains the engine and reports where its device time went: summed H2D copy durations (events on
+ * the copy stream) and bytes, summed tally-kernel durations and launches.  Any pointer may be NULL. */
+int pssbam_engine_phase_times(pssbam_engine *e, double *h2d_ms, uint64_t *h2d_bytes, double *kernel_ms,
+                              uint64_t *n_launches);
 
 /* Host helper: walks the block_size chain of an inflated BAM record stream.  Writes up
  * to max_records offsets (+ the end sentinel), returns the number of whole records

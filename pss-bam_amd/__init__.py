@@ -32,7 +32,8 @@ ST_N = 16
 HIP_SYMBOLS = [
     "pssbam_last_error", "pssbam_device_count", "pssbam_warmup", "pssbam_engine_create", "pssbam_engine_destroy",
     "pssbam_engine_set_stream", "pssbam_engine_set_genome", "pssbam_engine_set_genome_arrays",
-    "pssbam_engine_set_references", "pssbam_engine_submit", "pssbam_engine_submit_device", "pssbam_engine_sync",
+    "pssbam_engine_set_references", "pssbam_engine_submit", "pssbam_engine_submit_async", "pssbam_engine_wait_copied",
+    "pssbam_engine_copy_done", "pssbam_engine_phase_times", "pssbam_engine_submit_device", "pssbam_engine_sync",
     "pssbam_engine_finish", "pssbam_engine_reset", "pssbam_engine_counters_device", "pssbam_engine_bind_counters",
     "pssbam_reduce_counters", "pssbam_engine_genome_kmer_count", "pssbam_host_register", "pssbam_host_unregister", "pssbam_engine_timer_begin",
     "pssbam_engine_timer_end", "pssbam_engine_kernel_time", "pssbam_index_records",
@@ -86,6 +87,11 @@ def hip_lib() -> C.CDLL:
                                                   C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.c_int]
     L.pssbam_engine_set_references.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_char_p)]
     L.pssbam_engine_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32]
+    L.pssbam_engine_submit_async.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64)]
+    L.pssbam_engine_wait_copied.argtypes = [C.c_void_p, C.c_uint64]
+    L.pssbam_engine_copy_done.argtypes = [C.c_void_p, C.c_uint64]
+    L.pssbam_engine_phase_times.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_double),
+                                            C.POINTER(C.c_uint64)]
     L.pssbam_engine_submit_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32]
     L.pssbam_engine_sync.argtypes = [C.c_void_p]
     L.pssbam_engine_finish.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -209,6 +215,27 @@ class Engine:
         offsets = np.ascontiguousarray(offsets, dtype=np.uint32)
         _chk(self._L.pssbam_engine_submit(self._h, records.ctypes.data, records.size, offsets.ctypes.data,
                                           offsets.size - 1))
+
+    def submit_async(self, records: np.ndarray, offsets: np.ndarray) -> int:
+        """enqueue only; the arrays must stay alive and untouched until wait_copied(ticket)"""
+        t = C.c_uint64()
+        _chk(self._L.pssbam_engine_submit_async(self._h, records.ctypes.data, records.size, offsets.ctypes.data,
+                                                offsets.size - 1, C.byref(t)))
+        return int(t.value)
+
+    def wait_copied(self, ticket: int):
+        _chk(self._L.pssbam_engine_wait_copied(self._h, ticket))
+
+    def copy_done(self, ticket: int) -> bool:
+        rc = self._L.pssbam_engine_copy_done(self._h, ticket)
+        if rc < 0:
+            _chk(rc)
+        return bool(rc)
+
+    def phase_times(self) -> dict:
+        a, b, c, d = C.c_double(), C.c_uint64(), C.c_double(), C.c_uint64()
+        _chk(self._L.pssbam_engine_phase_times(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        return {"h2d_ms": a.value, "h2d_bytes": b.value, "kernel_ms": c.value, "launches": d.value}
 
     def submit_device(self, d_records: int, nbytes: int, d_offsets: int, n_records: int):
         _chk(self._L.pssbam_engine_submit_device(self._h, C.c_void_p(d_records), nbytes, C.c_void_p(d_offsets),

@@ -71,8 +71,10 @@ struct Slot {  // one in-flight host-submitted block
     size_t recs_cap = 0;
     uint32_t *d_offs = nullptr;
     size_t offs_cap = 0;  // entries
-    hipEvent_t copied = nullptr, consumed = nullptr;
+    hipEvent_t copy_begin = nullptr, copied = nullptr, consumed = nullptr;
     bool busy = false;
+    bool timed = false;       // copy_begin/copied hold an unread H2D duration
+    uint64_t ticket = 0;      // the submit that last used the slot
 };
 
 struct pssbam_engine {
@@ -109,6 +111,9 @@ struct pssbam_engine {
     // staging
     Slot slots[2];
     int next_slot = 0;
+    uint64_t ticket_seq = 0;
+    double h2d_ms = 0.0;      // summed H2D copy durations (events on the copy stream)
+    uint64_t h2d_bytes = 0;
     // timing
     hipEvent_t t_begin = nullptr, t_end = nullptr;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> launch_events;
@@ -209,7 +214,8 @@ extern "C" int pssbam_engine_create(const pssbam_config *cfg, pssbam_engine **ou
         HIP_TRY(hipMemcpy(e->d_rg, e->rg.data(), e->rg.size(), hipMemcpyHostToDevice));
     }
     for (Slot &s : e->slots) {
-        HIP_TRY(hipEventCreateWithFlags(&s.copied, hipEventDisableTiming));
+        HIP_TRY(hipEventCreate(&s.copy_begin));
+        HIP_TRY(hipEventCreate(&s.copied));
         HIP_TRY(hipEventCreateWithFlags(&s.consumed, hipEventDisableTiming));
     }
     e->env_tile_reads = env_int("PSSBAM_TILE_READS");
@@ -232,6 +238,7 @@ extern "C" void pssbam_engine_destroy(pssbam_engine *e) {
         if (s.d_recs) (void)hipFree(s.d_recs);
         if (s.d_offs) (void)hipFree(s.d_offs);
         if (s.copied) (void)hipEventDestroy(s.copied);
+        if (s.copy_begin) (void)hipEventDestroy(s.copy_begin);
         if (s.consumed) (void)hipEventDestroy(s.consumed);
     }
     for (auto &p : e->launch_events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
@@ -623,10 +630,19 @@ extern "C" int pssbam_engine_submit_device(pssbam_engine *e, const void *d_recor
     return launch_tally(e, (const uint8_t *)d_records, nbytes, d_offsets, n_records, nullptr, 0);
 }
 
-extern "C" int pssbam_engine_submit(pssbam_engine *e, const void *records, uint64_t nbytes, const uint32_t *offsets,
-                                    uint32_t n_records) {
+// books the H2D duration of a slot whose copy is known to be complete
+static void book_copy_time(pssbam_engine *e, Slot &s) {
+    if (!s.timed) return;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, s.copy_begin, s.copied) == hipSuccess) e->h2d_ms += ms;
+    s.timed = false;
+}
+
+extern "C" int pssbam_engine_submit_async(pssbam_engine *e, const void *records, uint64_t nbytes, const uint32_t *offsets,
+                                          uint32_t n_records, uint64_t *ticket) {
     int rc = check_ready(e);
     if (rc) return rc;
+    if (ticket) *ticket = 0;
     if (!n_records) return PSSBAM_OK;
     if (!records || !offsets) return fail(PSSBAM_EINVAL, "null buffer");
     if (nbytes >= (1ull << 32)) return fail(PSSBAM_EINVAL, "record block must be < 4 GiB (got %llu)", (unsigned long long)nbytes);
@@ -634,8 +650,9 @@ extern "C" int pssbam_engine_submit(pssbam_engine *e, const void *records, uint6
     HIP_TRY(hipSetDevice(e->device));
     Slot &s = e->slots[e->next_slot];
     e->next_slot ^= 1;
-    if (s.busy) HIP_TRY(hipEventSynchronize(s.consumed));  // the kernel that read this slot is done
+    if (s.busy) HIP_TRY(hipEventSynchronize(s.consumed));  // the kernel that read this slot is done (so is its copy)
     s.busy = false;
+    book_copy_time(e, s);
     if (s.recs_cap < nbytes + 64) {
         if (s.d_recs) HIP_TRY(hipFree(s.d_recs));
         s.d_recs = nullptr;
@@ -652,7 +669,9 @@ extern "C" int pssbam_engine_submit(pssbam_engine *e, const void *records, uint6
     // large blocks go over two copy streams (two DMA engines): one stream alone does not fill
     // the PCIe link
     const uint64_t half = (nbytes >= (64ull << 20) && !getenv("PSSBAM_ONE_COPY_STREAM")) ? (nbytes / 2) & ~4095ull : 0;
+    HIP_TRY(hipEventRecord(s.copy_begin, e->copy_stream));
     if (half) {
+        HIP_TRY(hipStreamWaitEvent(e->copy_stream2, s.copy_begin, 0));
         HIP_TRY(hipMemcpyAsync(s.d_recs + half, (const uint8_t *)records + half, nbytes - half, hipMemcpyHostToDevice, e->copy_stream2));
         HIP_TRY(hipEventRecord(e->copied2, e->copy_stream2));
     }
@@ -661,13 +680,66 @@ extern "C" int pssbam_engine_submit(pssbam_engine *e, const void *records, uint6
                            e->copy_stream));
     if (half) HIP_TRY(hipStreamWaitEvent(e->copy_stream, e->copied2, 0));  // `copied` then covers both halves
     HIP_TRY(hipEventRecord(s.copied, e->copy_stream));
+    s.timed = true;
+    e->h2d_bytes += nbytes + ((uint64_t)n_records + 1) * sizeof(uint32_t);
     HIP_TRY(hipStreamWaitEvent(e->stream, s.copied, 0));
     rc = launch_tally(e, s.d_recs, nbytes, s.d_offs, n_records, (const uint8_t *)records, nbytes);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(s.consumed, e->stream));
     s.busy = true;
+    s.ticket = ++e->ticket_seq;
+    if (ticket) *ticket = s.ticket;
+    return PSSBAM_OK;
+}
+
+// 1 = the copy of that submit has completed (its host buffers are free), 0 = still in flight
+extern "C" int pssbam_engine_copy_done(pssbam_engine *e, uint64_t ticket) {
+    if (!e) return fail(PSSBAM_EINVAL, "null engine");
+    if (!ticket) return 1;
+    for (Slot &s : e->slots)
+        if (s.ticket == ticket) {
+            HIP_TRY(hipSetDevice(e->device));
+            const hipError_t q = hipEventQuery(s.copied);
+            if (q == hipSuccess) return 1;
+            if (q == hipErrorNotReady) return 0;
+            return fail(PSSBAM_EHIP, "hipEventQuery failed: %s", hipGetErrorString(q));
+        }
+    return 1;  // the slot has been reused since: that submit waited for the kernel behind this copy
+}
+
+extern "C" int pssbam_engine_wait_copied(pssbam_engine *e, uint64_t ticket) {
+    if (!e) return fail(PSSBAM_EINVAL, "null engine");
+    if (!ticket) return PSSBAM_OK;
+    for (Slot &s : e->slots)
+        if (s.ticket == ticket) {
+            HIP_TRY(hipSetDevice(e->device));
+            HIP_TRY(hipEventSynchronize(s.copied));
+            return PSSBAM_OK;
+        }
+    return PSSBAM_OK;
+}
+
+extern "C" int pssbam_engine_submit(pssbam_engine *e, const void *records, uint64_t nbytes, const uint32_t *offsets,
+                                    uint32_t n_records) {
+    uint64_t ticket = 0;
+    int rc = pssbam_engine_submit_async(e, records, nbytes, offsets, n_records, &ticket);
+    if (rc) return rc;
     // contract: the caller's buffers are free for reuse when we return
-    HIP_TRY(hipEventSynchronize(s.copied));
+    return pssbam_engine_wait_copied(e, ticket);
+}
+
+extern "C" int pssbam_engine_phase_times(pssbam_engine *e, double *h2d_ms, uint64_t *h2d_bytes, double *kernel_ms,
+                                         uint64_t *n_launches) {
+    if (!e) return fail(PSSBAM_EINVAL, "null engine");
+    int rc = pssbam_engine_sync(e);
+    if (rc) return rc;
+    for (Slot &s : e->slots) book_copy_time(e, s);
+    rc = resolve_launch_events(e);
+    if (rc) return rc;
+    if (h2d_ms) *h2d_ms = e->h2d_ms;
+    if (h2d_bytes) *h2d_bytes = e->h2d_bytes;
+    if (kernel_ms) *kernel_ms = e->kernel_ms;
+    if (n_launches) *n_launches = e->kernel_launches;
     return PSSBAM_OK;
 }
 

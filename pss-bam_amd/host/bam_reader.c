@@ -60,7 +60,8 @@ typedef struct {
     uint32_t spec_end; /* where that walk stopped: isize, or the start of a record that runs on */
 } blk_t;
 
-#define N_SLOTS 3
+#define MAX_SLOTS 16
+#define N_SLOTS (r->n_slots)
 enum { SLOT_FREE = 0, SLOT_FILLED = 1, SLOT_READY = 2 };
 
 typedef struct {
@@ -91,9 +92,10 @@ struct bam_reader {
     uint8_t *ubase;
     size_t ucap;
     size_t gap;        /* bytes reserved in front of each slot's payload for the carry */
-    slot_t slot[N_SLOTS];
+    int n_slots;       /* batch slots in the ring (3 by default; more let a caller hold several batches) */
+    slot_t slot[MAX_SLOTS];
     int take;          /* slot the next bam_reader_next() returns   */
-    int held;          /* slot the caller is working on, or -1      */
+    int held;          /* slot handed out by bam_reader_next() (auto-released by the next call), or -1 */
     /* producer */
     pthread_t producer, indexer, prefault;
     int producer_started, indexer_started, prefault_started;
@@ -591,10 +593,17 @@ static int load_input(bam_reader *r, const char *path)
 
 bam_reader *bam_reader_open(const char *path, int n_threads, size_t batch_bytes, char *err, size_t errlen)
 {
+    return bam_reader_open_slots(path, n_threads, batch_bytes, 0, err, errlen);
+}
+
+bam_reader *bam_reader_open_slots(const char *path, int n_threads, size_t batch_bytes, int n_slots, char *err, size_t errlen)
+{
     bam_reader *r = (bam_reader *)calloc(1, sizeof *r);
     if (!r) return NULL;
     r->fd = -1;
     r->held = -1;
+    if (n_slots <= 0 && getenv("PSSBAM_SLOTS")) n_slots = atoi(getenv("PSSBAM_SLOTS"));
+    r->n_slots = n_slots < 3 ? 3 : n_slots > MAX_SLOTS ? MAX_SLOTS : n_slots;
     atomic_store(&r->n_ref_known, -1);
     pthread_mutex_init(&r->mu, NULL);
     pthread_cond_init(&r->cv, NULL);
@@ -691,6 +700,34 @@ int64_t bam_reader_next(bam_reader *r, const uint8_t **records, const uint32_t *
     *nbytes = s->rec_end - s->start;
     return (int64_t)s->n_recs;
 }
+
+int64_t bam_reader_next_hold(bam_reader *r, const uint8_t **records, const uint32_t **offsets, size_t *nbytes, int *slot_id)
+{
+    pthread_mutex_lock(&r->mu);
+    slot_t *s = &r->slot[r->take];
+    while (s->state != SLOT_READY) pthread_cond_wait(&r->cv, &r->mu);
+    pthread_mutex_unlock(&r->mu);
+    *slot_id = -1;
+    if (s->rc) return -1;
+    if (s->eof) return 0;
+    *slot_id = r->take;
+    r->take = (r->take + 1) % N_SLOTS;
+    *records = s->buf + s->start;
+    *offsets = s->offs;
+    *nbytes = s->rec_end - s->start;
+    return (int64_t)s->n_recs;
+}
+
+void bam_reader_release(bam_reader *r, int slot_id)
+{
+    if (slot_id < 0 || slot_id >= N_SLOTS) return;
+    pthread_mutex_lock(&r->mu);
+    r->slot[slot_id].state = SLOT_FREE;
+    pthread_cond_broadcast(&r->cv);
+    pthread_mutex_unlock(&r->mu);
+}
+
+int bam_reader_slots(const bam_reader *r) { return r->n_slots; }
 
 void bam_reader_close(bam_reader *r)
 {

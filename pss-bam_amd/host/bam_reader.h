@@ -27,12 +27,23 @@ typedef struct bam_header {
  * batch buffers, two of them (0 = $PSSBAM_BATCH_BYTES or 256 MiB).  On failure returns NULL
  * and describes it in err. */
 bam_reader *bam_reader_open(const char *path, int n_threads, size_t batch_bytes, char *err, size_t errlen);
+/* The same with n_slots batch buffers in the ring instead of three (0 = $PSSBAM_SLOTS or 3, at most
+ * 16): a caller that keeps several batches in flight -- asynchronous copies to several GPUs --
+ * takes them with bam_reader_next_hold() and gives each back with bam_reader_release() once its
+ * copy has completed; the reader keeps two slots for its own fill/index stages. */
+bam_reader *bam_reader_open_slots(const char *path, int n_threads, size_t batch_bytes, int n_slots, char *err, size_t errlen);
+int bam_reader_slots(const bam_reader *r);
 const bam_header *bam_reader_header(const bam_reader *r);
 
 /* Next batch of whole alignment records.  *records points into the reader's own buffer
  * (valid until the next call), offsets[0..n] index it (offsets[n] == *nbytes).
  * Returns the record count, 0 at end of file, -1 on error (see bam_reader_error). */
 int64_t bam_reader_next(bam_reader *r, const uint8_t **records, const uint32_t **offsets, size_t *nbytes);
+
+/* Like bam_reader_next, but the batch stays valid until bam_reader_release(r, *slot_id); do not mix
+ * the two styles on one reader. */
+int64_t bam_reader_next_hold(bam_reader *r, const uint8_t **records, const uint32_t **offsets, size_t *nbytes, int *slot_id);
+void bam_reader_release(bam_reader *r, int slot_id);
 
 /* The batch buffer, so a caller can page-lock it for DMA (base, capacity). */
 void bam_reader_buffer(const bam_reader *r, void **base, size_t *bytes);

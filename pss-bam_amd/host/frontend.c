@@ -44,11 +44,27 @@ static void *warmup_main(void *arg)
     return NULL;
 }
 
+/* Feed geometry for n GPUs: every GPU is dealt runs of `run` consecutive batches (a sorted BAM then
+ * keeps each GPU's reference working set local) and up to n * run copies are in flight
+ * at once, so the reader ring needs that many slots plus two for its own fill / index stages. */
+static int feed_run(int n_gpus)
+{
+    const char *v = getenv("PSSBAM_RUN_BATCHES");
+    int run = v ? atoi(v) : (n_gpus > 1 ? 2 : 1);
+    return run < 1 ? 1 : run > 8 ? 8 : run;
+}
+
+static int feed_slots(int n_gpus)
+{
+    if (getenv("PSSBAM_SLOTS")) return 0; /* the reader reads the variable itself */
+    return n_gpus > 1 ? n_gpus * feed_run(n_gpus) + 2 : 3;
+}
+
 void frontend_warmup_start(const char *aln_path)
 {
     if (aln_path && strlen(aln_path) < sizeof early_path && file_is_bam(aln_path) == 1) {
         char err[256];
-        early_rd = bam_reader_open(aln_path, 0, 0, err, sizeof err); /* a failure is reported by run_tally's own open */
+        early_rd = bam_reader_open_slots(aln_path, 0, 0, feed_slots(env_gpu_count()), err, sizeof err); /* a failure is reported by run_tally's own open */
         if (early_rd) strcpy(early_path, aln_path);
     }
     warmup_running = pthread_create(&warmup_thread, NULL, warmup_main, NULL) == 0;
@@ -124,7 +140,7 @@ int run_tally(const pssbam_config *cfg, Genome *genome, const char *aln_path, in
             bam_reader_buffer(rd, &buf_base, &buf_bytes);
             registered = 1;
         }
-    } else if (is_bam) rd = bam_reader_open(aln_path, 0, 0, err, sizeof err);
+    } else if (is_bam) rd = bam_reader_open_slots(aln_path, 0, 0, feed_slots(n_gpus), err, sizeof err);
     else sd = sam_reader_open(aln_path, 0, err, sizeof err);
     if (!rd && !sd) {
         fprintf(stderr, "Error: Unable to open %s: %s\n", aln_path, err);
@@ -147,18 +163,58 @@ int run_tally(const pssbam_config *cfg, Genome *genome, const char *aln_path, in
     }
     t_register = now_s() - t_mark;
 
+    /* Batches in flight: (reader slot, engine, ticket).  A BAM batch is handed to its engine without
+     * waiting for the copy (pssbam_engine_submit_async) and its slot goes back to the reader when
+     * the copy has completed -- so the PCIe links of different GPUs carry copies at the same time
+     * and one host thread is enough to deal them.  SAM text keeps the blocking submit. */
+    struct { int slot, g; uint64_t ticket; double t_issue, t_done; } fifo[64];
+    int fifo_head = 0, fifo_len = 0;
+    const int run = feed_run(n_gpus);
+    const int max_inflight = rd ? (bam_reader_slots(rd) - 2 < 1 ? 1 : bam_reader_slots(rd) - 2 > 62 ? 62 : bam_reader_slots(rd) - 2) : 0;
+    double overlap_s = 0.0, win_lo[64], win_hi[64]; /* last copy window seen per engine */
+    for (int g = 0; g < 64; g++) win_lo[g] = win_hi[g] = -1.0;
+    uint64_t n_batches = 0;
+#define RETIRE_OLDEST()                                                                                        \
+    do {                                                                                                       \
+        const int k = fifo_head;                                                                               \
+        if (pssbam_engine_wait_copied(eng[fifo[k].g], fifo[k].ticket)) {                                       \
+            fprintf(stderr, "Error: GPU engine: %s\n", pssbam_last_error());                                   \
+            goto done;                                                                                         \
+        }                                                                                                      \
+        if (fifo[k].t_done < 0) fifo[k].t_done = now_s();                                                      \
+        bam_reader_release(rd, fifo[k].slot);                                                                  \
+        if (verbose && n_gpus > 1) {                                                                           \
+            /* time this copy window shares with the latest window of every other engine */                    \
+            for (int o = 0; o < n_gpus; o++) {                                                                 \
+                if (o == fifo[k].g || win_hi[o] < 0) continue;                                                 \
+                const double lo = fifo[k].t_issue > win_lo[o] ? fifo[k].t_issue : win_lo[o];                   \
+                const double hi = fifo[k].t_done < win_hi[o] ? fifo[k].t_done : win_hi[o];                     \
+                if (hi > lo) overlap_s += hi - lo;                                                             \
+            }                                                                                                  \
+            if (n_batches <= 24)                                                                               \
+                fprintf(stderr, "[pssbam] copy window: engine %d  %.4f .. %.4f s\n", fifo[k].g, fifo[k].t_issue - t0, \
+                        fifo[k].t_done - t0);                                                                  \
+            win_lo[fifo[k].g] = fifo[k].t_issue;                                                               \
+            win_hi[fifo[k].g] = fifo[k].t_done;                                                                \
+        }                                                                                                      \
+        fifo_head = (fifo_head + 1) % 64;                                                                      \
+        fifo_len--;                                                                                            \
+    } while (0)
+
     for (int turn = 0;; turn++) {
         const uint8_t *recs;
         const uint32_t *offs;
         size_t nbytes;
+        int slot = -1;
         t_mark = now_s();
-        int64_t n = rd ? bam_reader_next(rd, &recs, &offs, &nbytes) : sam_reader_next(sd, &recs, &offs, &nbytes);
+        int64_t n = rd ? bam_reader_next_hold(rd, &recs, &offs, &nbytes, &slot) : sam_reader_next(sd, &recs, &offs, &nbytes);
         t_read += now_s() - t_mark; t_mark = now_s();
         if (n < 0) {
             fprintf(stderr, "Error: %s: %s\n", aln_path, rd ? bam_reader_error(rd) : sam_reader_error(sd));
             goto done;
         }
         if (n == 0) break;
+        n_batches++;
         /* reference names: fixed by the BAM header; for SAM text the table grows as new RNAMEs
          * show up, so it is (re)sent whenever it changed */
         const int32_t n_ref = rd ? bam_reader_header(rd)->n_ref : sam_reader_n_ref(sd);
@@ -171,12 +227,34 @@ int run_tally(const pssbam_config *cfg, Genome *genome, const char *aln_path, in
                 }
             refs_sent = n_ref;
         }
-        if (pssbam_engine_submit(eng[turn % n_gpus], recs, nbytes, offs, (uint32_t)n)) {
+        const int g = (turn / run) % n_gpus;
+        if (rd) {
+            uint64_t ticket = 0;
+            const double t_issue = now_s();
+            if (pssbam_engine_submit_async(eng[g], recs, nbytes, offs, (uint32_t)n, &ticket)) {
+                fprintf(stderr, "Error: GPU engine: %s\n", pssbam_last_error());
+                goto done;
+            }
+            const int k = (fifo_head + fifo_len) % 64;
+            fifo[k].slot = slot; fifo[k].g = g; fifo[k].ticket = ticket; fifo[k].t_issue = t_issue; fifo[k].t_done = -1.0;
+            fifo_len++;
+            if (verbose && n_gpus > 1) /* note completions as they are seen (the windows printed with PSSBAM_STATS) */
+                for (int i = 0; i < fifo_len; i++) {
+                    const int q = (fifo_head + i) % 64;
+                    if (fifo[q].t_done < 0 && pssbam_engine_copy_done(eng[fifo[q].g], fifo[q].ticket) == 1) fifo[q].t_done = now_s();
+                }
+            while (fifo_len > max_inflight) RETIRE_OLDEST();
+        } else if (pssbam_engine_submit(eng[g], recs, nbytes, offs, (uint32_t)n)) {
             fprintf(stderr, "Error: GPU engine: %s\n", pssbam_last_error());
             goto done;
         }
         t_submit += now_s() - t_mark;
     }
+    while (fifo_len > 0) RETIRE_OLDEST();
+#undef RETIRE_OLDEST
+    if (verbose && n_gpus > 1)
+        fprintf(stderr, "[pssbam] feed: %llu batches in runs of %d over %d engines, up to %d copies in flight; copy windows of "
+                        "different engines overlapped for %.3f s\n", (unsigned long long)n_batches, run, n_gpus, max_inflight, overlap_s);
     t_mark = now_s();
     if (refs_sent < 0) { /* no alignment at all: the engines still need a (possibly empty) table to finish */
         const int32_t n_ref = rd ? bam_reader_header(rd)->n_ref : sam_reader_n_ref(sd);
@@ -202,6 +280,18 @@ int run_tally(const pssbam_config *cfg, Genome *genome, const char *aln_path, in
         goto done;
     }
     t_finish = now_s() - t_mark;
+    if (verbose) {
+        double h2d = 0, ker = 0;
+        uint64_t bytes = 0, launches = 0;
+        for (int g = 0; g < n_gpus; g++) {
+            double a = 0, c = 0;
+            uint64_t b = 0, d = 0;
+            if (pssbam_engine_phase_times(eng[g], &a, &b, &c, &d) == 0) { h2d += a; bytes += b; ker += c; launches += d; }
+        }
+        fprintf(stderr, "[pssbam] device: h2d %.3f kernel %.3f s\n", h2d * 1e-3, ker * 1e-3);
+        fprintf(stderr, "[pssbam] device detail: %.2f GB copied (%.1f GB/s while copying), %llu tally launches\n", bytes * 1e-9,
+                h2d > 0 ? bytes * 1e-6 / h2d : 0.0, (unsigned long long)launches);
+    }
     if (verbose)
         fprintf(stderr, "[pssbam] phases: open %.3f engine+genome %.3f pin %.3f read(wait) %.3f submit %.3f reduce+finish %.3f s\n",
                 t_open, t_engine, t_register, t_read, t_submit, t_finish);

@@ -115,6 +115,26 @@ def test_cli_on_generated_bam_vs_oracle(bins, oracle, tmp_path):
         gf, gr = tl.parse_counts_text((tmp_path / "out3.pss.counts.txt").read_text())
         assert np.array_equal(gf, wf) and np.array_equal(gr, wr)
         assert f"records={n}" in pr.stderr
+        # the feed is asynchronous: runs of 2 batches per engine, 3 * 2 copies in flight, and the copy
+        # windows of different engines overlap in time (they used to be strictly serial)
+        import re
+        m = re.search(r"feed: (\d+) batches in runs of (\d+) over 3 engines, up to (\d+) copies in flight; copy windows of "
+                      r"different engines overlapped for ([\d.]+) s", pr.stderr)
+        assert m, pr.stderr[-2000:]
+        assert int(m.group(1)) >= 12 and int(m.group(2)) == 2 and int(m.group(3)) == 6
+        wins = [(int(g), float(a), float(b)) for g, a, b in re.findall(r"copy window: engine (\d)  ([\d.]+) \.\. ([\d.]+) s", pr.stderr)]
+        assert {g for g, _, _ in wins} == {0, 1, 2}
+        assert [g for g, _, _ in wins[:6]] == [0, 0, 1, 1, 2, 2]          # contiguous runs, not round-robin
+        assert any(a1 < b0 and a0 < b1 for (g0, a0, b0) in wins for (g1, a1, b1) in wins if g0 != g1), wins
+        assert float(m.group(4)) > 0
+    # and a run length of 1 / other geometries give the same tables
+    for extra in ({"PSSBAM_RUN_BATCHES": "1"}, {"PSSBAM_RUN_BATCHES": "3", "PSSBAM_SLOTS": "4"}):
+        env = {**os.environ, "PSSBAM_NGPU": "2", "PSSBAM_OVERSUBSCRIBE": "1", "PSSBAM_BATCH_BYTES": str(1 << 20), **extra}
+        pr = subprocess.run([str(bins / "pss-bam"), "-F", str(fa), "-B", str(bam), "-o", str(tmp_path / "out4")] + po.argv(),
+                            capture_output=True, text=True, env=env)
+        assert pr.returncode == 0, pr.stderr
+        gf, gr = tl.parse_counts_text((tmp_path / "out4.pss.counts.txt").read_text())
+        assert np.array_equal(gf, wf) and np.array_equal(gr, wr)
 
 
 def test_reduce_counters_single_engine_is_identity(tmp_path):
