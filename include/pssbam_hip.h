@@ -207,6 +207,37 @@ int pssbam_engine_kernel_time(pssbam_engine *e, double *total_ms, uint64_t *n_la
 int pssbam_engine_phase_times(pssbam_engine *e, double *h2d_ms, uint64_t *h2d_bytes, double *kernel_ms,
                               uint64_t *n_launches);
 
+/* ---- device-side BGZF inflate (second half) --------------------------------------
+ * What it replaces: the `samtools view` child that decompresses the BAM for the reference
+ * (/root/reference/pss-bam.c:148-162) -- here the compressed file crosses PCIe and every BGZF
+ * block (SAM spec 4.1; raw DEFLATE, RFC 1951) is inflated on the GPU, one lane per block. */
+typedef struct pssbam_bgzf_block {
+    uint64_t in_off;   /* offset of the block's raw deflate payload in the compressed buffer   */
+    uint32_t in_len;   /* payload bytes                                                        */
+    uint32_t isize;    /* ISIZE: bytes the block inflates to (<= 65536)                        */
+    uint64_t out_off;  /* where they go in the output buffer                                   */
+    uint32_t crc;      /* CRC-32 of the inflated bytes, from the block trailer                 */
+    uint32_t status;   /* out: 0 = ok, else which check failed (1..8, csrc/inflate_kernels.h)  */
+} pssbam_bgzf_block;
+
+/* Walks the BGZF headers of bytes[0..nbytes): fills blocks[] (out_off = running sum of ISIZE) up to
+ * max_blocks (blocks == NULL: count only), stops at the first partial block.  Returns the number
+ * of whole blocks or PSSBAM_EFORMAT; *consumed = bytes they cover, *inflated_bytes = sum of ISIZE. */
+int64_t pssbam_bgzf_scan(const void *bytes, uint64_t nbytes, pssbam_bgzf_block *blocks, uint64_t max_blocks,
+                         uint64_t *consumed, uint64_t *inflated_bytes);
+
+/* Inflates n_blocks blocks on the current device, asynchronously on hip_stream: d_comp (4-byte
+ * aligned, readable 4 bytes past comp_bytes) -> d_out at each block's out_off; d_blocks[i].status
+ * tells how block i went (check_crc != 0 adds the ISIZE/CRC-32 kernel). */
+int pssbam_bgzf_inflate_device(void *hip_stream, const void *d_comp, uint64_t comp_bytes, pssbam_bgzf_block *d_blocks,
+                               uint32_t n_blocks, void *d_out, int check_crc);
+
+/* Test / tool convenience: host BGZF bytes in, inflated bytes out (out may be NULL), kernels timed
+ * with HIP events (*kernel_ms = best of `repeats` runs of inflate + CRC). */
+int pssbam_bgzf_inflate_host(int device, const void *bgzf, uint64_t nbytes, void *out, uint64_t out_cap, uint64_t *out_len,
+                             uint32_t *n_blocks, uint32_t *first_bad_block, uint32_t *first_bad_status, double *kernel_ms,
+                             int check_crc, int repeats);
+
 /* Host helper: walks the block_size chain of an inflated BAM record stream.  Writes up
  * to max_records offsets (+ the end sentinel), returns the number of whole records
  * found (>= 0) or PSSBAM_EFORMAT; *consumed = bytes covered by those records. */

@@ -36,7 +36,8 @@ HIP_SYMBOLS = [
     "pssbam_engine_copy_done", "pssbam_engine_phase_times", "pssbam_engine_submit_device", "pssbam_engine_sync",
     "pssbam_engine_finish", "pssbam_engine_reset", "pssbam_engine_counters_device", "pssbam_engine_bind_counters",
     "pssbam_reduce_counters", "pssbam_engine_genome_kmer_count", "pssbam_host_register", "pssbam_host_unregister", "pssbam_engine_timer_begin",
-    "pssbam_engine_timer_end", "pssbam_engine_kernel_time", "pssbam_index_records",
+    "pssbam_engine_timer_end", "pssbam_engine_kernel_time", "pssbam_index_records", "pssbam_bgzf_scan",
+    "pssbam_bgzf_inflate_device", "pssbam_bgzf_inflate_host",
 ]
 
 
@@ -111,6 +112,30 @@ def hip_lib() -> C.CDLL:
 def _chk(rc: int) -> None:
     if rc != 0:
         raise PssbamError(f"pssbam error {rc}: {hip_lib().pssbam_last_error().decode()}")
+
+
+def bgzf_inflate(bgzf: np.ndarray, check_crc: bool = True, repeats: int = 1, want_output: bool = True) -> dict:
+    """Inflates whole BGZF blocks on the GPU (pssbam_bgzf_inflate_host): {"data", "n_blocks", "bad_block",
+    "bad_status", "kernel_ms"}; bad_block is None when every block passed."""
+    L = hip_lib()
+    L.pssbam_bgzf_inflate_host.argtypes = [C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64),
+                                           C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                                           C.POINTER(C.c_double), C.c_int, C.c_int]
+    L.pssbam_bgzf_scan.restype = C.c_int64
+    L.pssbam_bgzf_scan.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    bgzf = np.ascontiguousarray(bgzf, dtype=np.uint8)
+    consumed, total = C.c_uint64(), C.c_uint64()
+    n = L.pssbam_bgzf_scan(bgzf.ctypes.data, bgzf.size, None, 0, C.byref(consumed), C.byref(total))
+    if n < 0:
+        _chk(int(n))
+    out = np.empty(int(total.value) if want_output else 0, dtype=np.uint8)
+    out_len, nb, bad_b, bad_s, ms = C.c_uint64(), C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_double()
+    _chk(L.pssbam_bgzf_inflate_host(-1, bgzf.ctypes.data, bgzf.size, out.ctypes.data if want_output else None, out.size,
+                                    C.byref(out_len), C.byref(nb), C.byref(bad_b), C.byref(bad_s), C.byref(ms),
+                                    int(check_crc), repeats))
+    return {"data": out, "inflated_bytes": int(out_len.value), "n_blocks": int(nb.value),
+            "bad_block": None if bad_b.value == 0xFFFFFFFF else int(bad_b.value), "bad_status": int(bad_s.value),
+            "kernel_ms": float(ms.value)}
 
 
 def index_records(buf: np.ndarray) -> np.ndarray:

@@ -1003,3 +1003,8 @@ extern "C" int64_t pssbam_index_records(const void *bytes, uint64_t nbytes, uint
     if (consumed) *consumed = o;
     return (int64_t)n;
 }
+
+// --------------------------------------------------------------------------------------
+// device-side BGZF inflate
+// --------------------------------------------------------------------------------------
+#include "bgzf_api.h"

@@ -1,0 +1,438 @@
+// pss-bam_amd/csrc/inflate_kernels.h -- BGZF payload inflate (RFC 1951) + CRC-32 on gfx950.
+//
+// What it replaces: the `samtools view` child of the reference decompresses the BAM on the host
+// (/root/reference/pss-bam.c:148-162); round 1 moved that to host threads (host/inflate_fast.c),
+// which leaves PCIe carrying INFLATED bytes.  With these kernels the link carries
+// the compressed file and the blocks are inflated where the tally kernels read them.
+//
+// Mapping: ONE LANE PER BGZF BLOCK.  A BAM is hundreds of thousands of independent <= 64 KiB
+// deflate streams, and Huffman decoding is a serial chain per stream; rather than fight the
+// chain inside a block, every lane owns a whole block and walks it with plain SIMT code --
+// 64 blocks per wave, the wave diverging between "literal" and "match" like any branchy kernel.
+//   * per-lane decode tables in LDS, lane-interleaved (entry i of lane l at [i][l]): canonical
+//     Huffman data only -- sorted symbols + one offset per code length (736 B per lane, 46 KiB per
+//     wave, three waves per CU);
+//   * a symbol's code length comes from 15 register thresholds (canonical codes are ordered:
+//     the length is the number of left-aligned upper bounds the next 15 stream bits reach), so
+//     decoding a symbol is ~40 VALU + two LDS reads, with no loop and no per-length divergence;
+//   * the dynamic block header is parsed twice (count, then place) instead of storing 320 code
+//     lengths per lane;
+//   * 64-bit bit buffer refilled by aligned dword loads; matches with distance >= 8 move 8 bytes
+//     per step, shorter distances are expanded from a periodic 8-byte register pattern (the
+//     QUAL runs of a BAM are distance-1 matches: no load-after-store chain);
+//   * every access is bounded: reads inside the block's payload (+ one dword of slack the caller
+//     provides), writes inside [out_off, out_off + isize); a malformed stream sets the block's
+//     status and stops that lane.
+// A second kernel checks ISIZE/CRC-32 per block (wave per block, 1 KiB chunks per lane, chunk
+// CRCs combined by multiplication with x^(8*bytes behind the chunk) mod P).
+//
+// Bound: latency (LDS + L2 round trips on a serial chain), hidden by block-level parallelism:
+// 3 waves x 64 lanes x 256 CUs = 49 152 streams in flight.  Integer/bit work; no MFMA.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pssbam {
+
+struct BgzfBlock {       // one BGZF block, as the host's header walk found it
+    uint64_t in_off;     // offset of the raw deflate payload in the compressed buffer
+    uint32_t in_len;     // payload bytes (block length - header - 8-byte trailer)
+    uint32_t isize;      // ISIZE from the trailer: bytes this block inflates to
+    uint64_t out_off;    // where they go in the output buffer
+    uint32_t crc;        // CRC-32 from the trailer
+    uint32_t status;     // out: 0 ok, else INF_*
+};
+
+enum : uint32_t { INF_OK = 0, INF_BAD_BLOCK = 1, INF_BAD_CODES = 2, INF_BAD_SYMBOL = 3, INF_BAD_DISTANCE = 4, INF_OVERRUN = 5,
+                  INF_SHORT = 6, INF_TRUNCATED = 7, INF_BAD_CRC = 8 };
+
+constexpr int INF_WAVE = 64;
+// per-lane LDS, in u16 entries (lane-interleaved)
+constexpr int L_DELTA = 0;        // [16]  litlen: sorted-symbol index base minus first code, per code length
+constexpr int L_OFFS = 16;        // [16]  scratch while a table is built: next free slot per code length
+constexpr int L_SYM = 32;         // [288] litlen symbols sorted by (code length, symbol)
+constexpr int D_DELTA = 320;      // [16]  distance
+constexpr int D_SYM = 336;        // [32]  distance symbols (also hosts the 19-symbol code-length code)
+constexpr int INF_LDS_U16 = 368;  // 736 B per lane
+constexpr uint32_t INF_LDS_BYTES = INF_LDS_U16 * INF_WAVE * 2;
+
+struct LaneLds {  // this lane's view of the interleaved table
+    uint16_t *base;
+    __device__ __forceinline__ uint16_t &at(int i) const { return base[i * INF_WAVE]; }
+};
+
+struct BitReader {
+    const uint32_t *p;     // next aligned dword
+    const uint32_t *end;   // first dword that must not be read
+    uint64_t buf;
+    uint32_t cnt;          // valid bits in buf
+    uint64_t consumed;     // bits handed out
+    uint64_t limit;        // payload bits
+
+    __device__ __forceinline__ void refill() {
+        if (cnt <= 32u) {
+            const uint32_t w = p < end ? *p : 0u;
+            p++;
+            buf |= (uint64_t)w << cnt;
+            cnt += 32u;
+        }
+    }
+    __device__ __forceinline__ uint32_t peek15() const { return __brev((uint32_t)buf) >> 17; }  // first-read bit = MSB
+    __device__ __forceinline__ void drop(uint32_t n) { buf >>= n; cnt -= n; consumed += n; }
+    __device__ __forceinline__ uint32_t take(uint32_t n) {  // n <= 16, caller has refilled
+        const uint32_t v = (uint32_t)buf & ((1u << n) - 1u);
+        drop(n);
+        return v;
+    }
+    __device__ __forceinline__ bool overrun() const { return consumed > limit; }
+};
+
+// Canonical Huffman: builds upper[] (registers) and delta[] (LDS) from the per-length counts in
+// LDS at cnt_at (which it turns into the next-free-slot table offs[]).  false = over-subscribed.
+template <int MAXL>
+__device__ __forceinline__ bool huff_finish(const LaneLds &t, int cnt_at, int delta_at, uint32_t (&upper)[15]) {
+    uint32_t first = 0u, index = 0u;
+    bool ok = true;
+#pragma unroll
+    for (int L = 1; L <= 15; L++) {
+        if (L <= MAXL) {
+            const uint32_t c = t.at(cnt_at + L);
+            const uint32_t up = first + c;
+            ok = ok && up <= (1u << L);
+            upper[L - 1] = up << (15 - L);
+            t.at(delta_at + L) = (uint16_t)(index - first);   // mod 2^16: added back to a 16-bit code value
+            t.at(cnt_at + L) = (uint16_t)index;               // offs[L]
+            index += c;
+            first = up << 1;
+        } else {
+            upper[L - 1] = upper[MAXL - 1];
+        }
+    }
+    return ok;
+}
+
+// symbol for the next code of the stream; < 0: the bits are no code of this table
+template <int MAXL>
+__device__ __forceinline__ int huff_decode(BitReader &br, const LaneLds &t, int delta_at, int sym_at, int n_sym,
+                                           const uint32_t (&upper)[15]) {
+    const uint32_t c15 = br.peek15();
+    uint32_t L = 1u;
+#pragma unroll
+    for (int k = 0; k < MAXL; k++) L += c15 >= upper[k] ? 1u : 0u;
+    if (L > (uint32_t)MAXL) return -1;
+    const uint32_t idx = ((c15 >> (15u - L)) + t.at(delta_at + (int)L)) & 0xFFFFu;
+    if (idx >= (uint32_t)n_sym) return -1;
+    br.drop(L);
+    return (int)t.at(sym_at + (int)idx);
+}
+
+__device__ __forceinline__ uint64_t load_u64(const uint8_t *p) {
+    uint64_t v;
+    __builtin_memcpy(&v, p, 8);
+    return v;
+}
+__device__ __forceinline__ void store_u64(uint8_t *p, uint64_t v) { __builtin_memcpy(p, &v, 8); }
+
+// One BGZF block by one lane.  Returns INF_*.
+__device__ uint32_t inflate_block(const uint8_t *comp, uint64_t comp_bytes, const BgzfBlock &b, uint8_t *outbuf, const LaneLds &t) {
+    uint8_t *out = outbuf + b.out_off;
+    const uint32_t isize = b.isize;
+    BitReader br;
+    {
+        const uint64_t a = b.in_off;
+        br.p = (const uint32_t *)(comp + (a & ~3ull));
+        br.end = (const uint32_t *)(comp + ((comp_bytes + 3ull) & ~3ull));
+        br.buf = 0;
+        br.cnt = 0;
+        br.consumed = 0;
+        br.limit = (uint64_t)b.in_len * 8ull;
+        br.refill();
+        const uint32_t skip = 8u * (uint32_t)(a & 3ull);
+        br.buf >>= skip;
+        br.cnt -= skip;
+    }
+    uint32_t pos = 0;
+    uint32_t lu[15], du[15];   // code-length thresholds of the literal/length and distance codes
+    for (;;) {
+        br.refill();
+        const uint32_t bfinal = br.take(1), btype = br.take(2);
+        if (btype == 0u) {
+            // stored: skip to the byte boundary, LEN / NLEN, LEN raw bytes
+            br.drop(br.cnt & 7u);
+            br.refill();
+            const uint32_t len = br.take(16);
+            br.refill();
+            const uint32_t nlen = br.take(16);
+            if ((len ^ nlen) != 0xFFFFu) return INF_BAD_BLOCK;
+            if (len > isize - pos) return INF_OVERRUN;
+            if (br.consumed + (uint64_t)len * 8ull > br.limit) return INF_TRUNCATED;
+            for (uint32_t i = 0; i < len; i++) {   // byte-aligned from here: a byte at a time through the bit buffer
+                br.refill();
+                out[pos++] = (uint8_t)br.take(8);
+            }
+        } else if (btype == 1u || btype == 2u) {
+            if (btype == 1u) {
+                // fixed code (RFC 1951 3.2.6): lengths 8 x144, 9 x112, 7 x24, 8 x8; 30 distance codes of 5 bits
+#pragma unroll
+                for (int L = 0; L < 16; L++) { t.at(L_OFFS + L) = 0; t.at(D_DELTA + L) = 0; }
+                t.at(L_OFFS + 7) = 24; t.at(L_OFFS + 8) = 152; t.at(L_OFFS + 9) = 112;
+                (void)huff_finish<15>(t, L_OFFS, L_DELTA, lu);
+                for (int s = 0; s < 288; s++) {
+                    const int L = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8;
+                    const uint32_t o = t.at(L_OFFS + L);
+                    t.at(L_SYM + (int)o) = (uint16_t)s;
+                    t.at(L_OFFS + L) = (uint16_t)(o + 1u);
+                }
+#pragma unroll
+                for (int L = 0; L < 16; L++) t.at(L_OFFS + L) = 0;
+                t.at(L_OFFS + 5) = 30;
+                (void)huff_finish<15>(t, L_OFFS, D_DELTA, du);
+                for (int s = 0; s < 30; s++) t.at(D_SYM + s) = (uint16_t)s;
+            } else {
+                // dynamic code: HLIT, HDIST, HCLEN, the code-length code, then the two codes' lengths
+                br.refill();
+                const uint32_t nlen = br.take(5) + 257u, ndist = br.take(5) + 1u, ncode = br.take(4) + 4u;
+                if (nlen > 286u || ndist > 30u) return INF_BAD_CODES;
+                uint32_t cu[15];
+                uint64_t cl_packed = 0;   // the code-length code's own lengths, 3 bits each, by symbol
+                {
+#pragma unroll
+                    for (int L = 0; L < 16; L++) t.at(L_OFFS + L) = 0;
+                    for (uint32_t i = 0; i < ncode; i++) {
+                        br.refill();
+                        const uint32_t l = br.take(3);
+                        // position of code-length symbol: 16,17,18,0,8,7,9,6,10,5,11,4,12,3,13,2,14,1,15
+                        const uint32_t sym = (uint32_t)((0xF1E2D3C4B5A69780ull >> (4u * (i >= 3u ? i - 3u : 0u))) & 15ull);
+                        const uint32_t s = i < 3u ? 16u + i : sym;
+                        cl_packed |= (uint64_t)l << (3u * s);
+                        if (l) t.at(L_OFFS + (int)l) = (uint16_t)(t.at(L_OFFS + (int)l) + 1u);
+                    }
+                    if (!huff_finish<7>(t, L_OFFS, D_DELTA, cu)) return INF_BAD_CODES;
+                    for (uint32_t s = 0; s < 19u; s++) {
+                        const uint32_t l = (uint32_t)(cl_packed >> (3u * s)) & 7u;
+                        if (l) {
+                            const uint32_t o = t.at(L_OFFS + (int)l);
+                            t.at(D_SYM + (int)o) = (uint16_t)s;
+                            t.at(L_OFFS + (int)l) = (uint16_t)(o + 1u);
+                        }
+                    }
+                }
+                // the nlen + ndist code lengths are walked twice from the same stream position: pass 0
+                // counts them per length, pass 1 places the symbols (no per-lane array of 320 lengths)
+                const BitReader mark = br;
+                uint16_t lcount[16], dcount[16];   // pass 0 results (registers: static indices only below)
+                uint32_t n_cl_sym = 0;   // symbols the code-length code actually has
+                for (uint32_t s = 0; s < 19u; s++) n_cl_sym += ((cl_packed >> (3u * s)) & 7u) ? 1u : 0u;
+                for (int pass = 0; pass < 2; pass++) {
+                    if (pass == 1) {
+                        // counts -> tables.  The code-length code's D_DELTA/D_SYM entries are still needed for
+                        // pass 1, so the distance table is finished after the walk; litlen can be finished now
+                        br = mark;
+#pragma unroll
+                        for (int L = 0; L < 16; L++) t.at(L_OFFS + L) = lcount[L];
+                        if (!huff_finish<15>(t, L_OFFS, L_DELTA, lu)) return INF_BAD_CODES;
+                    } else {
+#pragma unroll
+                        for (int L = 0; L < 16; L++) { lcount[L] = 0; dcount[L] = 0; }
+                    }
+                    uint32_t idx = 0, prev = 0;
+                    // distance symbols cannot be placed while D_SYM holds the code-length code: their
+                    // lengths are remembered as 30 nibbles (two registers)
+                    uint64_t dl_lo = 0, dl_hi = 0;
+                    while (idx < nlen + ndist) {
+                        br.refill();
+                        const int sym = huff_decode<7>(br, t, D_DELTA, D_SYM, (int)n_cl_sym, cu);
+                        if (sym < 0) return INF_BAD_CODES;
+                        uint32_t len = (uint32_t)sym, rep = 1u;
+                        if (sym >= 16) {
+                            if (sym == 16) { if (idx == 0u) return INF_BAD_CODES; len = prev; rep = 3u + br.take(2); }
+                            else if (sym == 17) { len = 0u; rep = 3u + br.take(3); }
+                            else { len = 0u; rep = 11u + br.take(7); }
+                        }
+                        if (idx + rep > nlen + ndist) return INF_BAD_CODES;
+                        prev = len;
+                        for (uint32_t r = 0; r < rep; r++, idx++) {
+                            if (!len) continue;
+                            if (idx < nlen) {
+                                if (pass == 0) {
+#pragma unroll
+                                    for (int L = 1; L < 16; L++) lcount[L] = (uint16_t)(lcount[L] + ((uint32_t)L == len ? 1u : 0u));
+                                } else {
+                                    const uint32_t o = t.at(L_OFFS + (int)len);
+                                    t.at(L_SYM + (int)o) = (uint16_t)idx;
+                                    t.at(L_OFFS + (int)len) = (uint16_t)(o + 1u);
+                                }
+                            } else {
+                                const uint32_t d = idx - nlen;
+                                if (pass == 0) {
+#pragma unroll
+                                    for (int L = 1; L < 16; L++) dcount[L] = (uint16_t)(dcount[L] + ((uint32_t)L == len ? 1u : 0u));
+                                } else {
+                                    if (d < 16u) dl_lo |= (uint64_t)len << (4u * d);
+                                    else dl_hi |= (uint64_t)len << (4u * (d - 16u));
+                                }
+                            }
+                        }
+                    }
+                    if (br.overrun()) return INF_TRUNCATED;
+                    if (pass == 1) {
+                        // now the distance code: counts -> thresholds, then place its symbols
+#pragma unroll
+                        for (int L = 0; L < 16; L++) t.at(L_OFFS + L) = dcount[L];
+                        if (!huff_finish<15>(t, L_OFFS, D_DELTA, du)) return INF_BAD_CODES;
+                        for (uint32_t d = 0; d < ndist; d++) {
+                            const uint32_t l = (uint32_t)((d < 16u ? dl_lo >> (4u * d) : dl_hi >> (4u * (d - 16u))) & 15ull);
+                            if (l) {
+                                const uint32_t o = t.at(L_OFFS + (int)l);
+                                t.at(D_SYM + (int)o) = (uint16_t)d;
+                                t.at(L_OFFS + (int)l) = (uint16_t)(o + 1u);
+                            }
+                        }
+                    }
+                }
+            }
+            // ---- the compressed data of this deflate block ------------------------------------
+            for (;;) {
+                br.refill();
+                const int sym = huff_decode<15>(br, t, L_DELTA, L_SYM, 288, lu);
+                if (sym < 0) return INF_BAD_SYMBOL;
+                if (sym < 256) {
+                    if (pos >= isize) return INF_OVERRUN;
+                    out[pos++] = (uint8_t)sym;
+                    continue;
+                }
+                if (sym == 256) break;
+                if (sym > 285) return INF_BAD_SYMBOL;
+                // length: 257..264 -> 3..10; 265..284 -> ((4 + (s-265)%4) << e) + 3 with e = (s-261)/4 extra bits; 285 -> 258
+                uint32_t len;
+                {
+                    const uint32_t s = (uint32_t)sym;
+                    if (s < 265u) len = s - 254u;
+                    else if (s == 285u) len = 258u;
+                    else {
+                        const uint32_t e = (s - 261u) >> 2;
+                        len = ((4u + ((s - 265u) & 3u)) << e) + 3u + br.take(e);
+                    }
+                }
+                br.refill();
+                const int ds = huff_decode<15>(br, t, D_DELTA, D_SYM, 30, du);
+                if (ds < 0) return INF_BAD_DISTANCE;
+                uint32_t dist;
+                {
+                    const uint32_t d = (uint32_t)ds;
+                    if (d < 4u) dist = d + 1u;
+                    else {
+                        const uint32_t e = (d >> 1) - 1u;
+                        dist = ((2u + (d & 1u)) << e) + 1u + br.take(e);
+                    }
+                }
+                if (dist > pos) return INF_BAD_DISTANCE;
+                if (len > isize - pos) return INF_OVERRUN;
+                uint8_t *dst = out + pos;
+                pos += len;
+                if (dist >= 8u) {
+                    const uint8_t *src = dst - dist;
+                    while (len >= 8u) { store_u64(dst, load_u64(src)); dst += 8; src += 8; len -= 8u; }
+                    for (uint32_t i = 0; i < len; i++) dst[i] = src[i];
+                } else {
+                    // periodic pattern of period `dist` in a register: no load-after-store chain
+                    uint64_t pat = 0;
+                    for (uint32_t i = 0; i < dist; i++) pat |= (uint64_t)dst[(int)i - (int)dist] << (8u * i);
+                    for (uint32_t w = dist; w < 8u; w <<= 1) pat |= pat << (8u * w);
+                    const uint32_t step = (8u / dist) * dist;   // whole periods per 8-byte store
+                    while (len >= 8u) { store_u64(dst, pat); dst += step; len -= step; }
+                    for (uint32_t i = 0; i < len; i++) dst[i] = (uint8_t)(pat >> (8u * i));
+                }
+            }
+            if (br.overrun()) return INF_TRUNCATED;
+        } else {
+            return INF_BAD_BLOCK;
+        }
+        if (bfinal) break;
+    }
+    if (br.overrun()) return INF_TRUNCATED;
+    return pos == isize ? INF_OK : INF_SHORT;
+}
+
+// grid of single-wave workgroups, each wave takes 64 consecutive blocks at a time
+__global__ void __launch_bounds__(INF_WAVE) bgzf_inflate_kernel(const uint8_t *comp, uint64_t comp_bytes, BgzfBlock *blocks,
+                                                                uint32_t n_blocks, uint8_t *out) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t inf_lds[];
+    const uint32_t lane = threadIdx.x;
+    const LaneLds t{inf_lds + lane};
+    for (uint32_t g = blockIdx.x; g * INF_WAVE < n_blocks; g += gridDim.x) {
+        const uint32_t i = g * INF_WAVE + lane;
+        if (i < n_blocks) {
+            const BgzfBlock b = blocks[i];
+            uint32_t st = INF_OK;
+            if (b.isize) st = inflate_block(comp, comp_bytes, b, out, t);
+            blocks[i].status = st;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// CRC-32 (IEEE 802.3, reflected, as gzip) of every inflated block
+// ---------------------------------------------------------------------------------------
+constexpr uint32_t CRC_POLY = 0xEDB88320u;
+constexpr uint32_t CRC_CHUNK = 1024;   // bytes per lane
+
+// a(x) * b(x) mod P in the reflected representation (bit 31 = x^0)
+__device__ __forceinline__ uint32_t gf2_mul(uint32_t a, uint32_t b) {
+    uint32_t r = 0u;
+#pragma unroll 8
+    for (int i = 0; i < 32; i++) {
+        r ^= (b & 0x80000000u) ? a : 0u;   // b's x^i term, i counted from bit 31
+        b <<= 1;
+        a = (a >> 1) ^ ((a & 1u) ? CRC_POLY : 0u);   // a *= x
+    }
+    return r;
+}
+
+// one wave per block: lane c owns the 1 KiB chunk that ends (63 - c) KiB before the block's end;
+// chunk CRCs (no pre/post conditioning except the 0xFFFFFFFF start on the first data byte) are
+// moved to the end of the block by multiplying with x^(8 * bytes behind the chunk) -- powers of
+// x^(8 * 1024) from a 64-entry table -- and XORed together.
+__global__ void __launch_bounds__(256) bgzf_crc_kernel(const uint8_t *out, BgzfBlock *blocks, uint32_t n_blocks,
+                                                       const uint32_t *xpow_kib /* [64]: x^(8*1024*k) mod P */) {
+    __shared__ uint32_t tab[4][256];
+    for (uint32_t i = threadIdx.x; i < 256u; i += blockDim.x) {
+        uint32_t c = i;
+        for (int k = 0; k < 8; k++) c = (c >> 1) ^ ((c & 1u) ? CRC_POLY : 0u);
+        tab[0][i] = c;
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < 256u; i += blockDim.x) {
+        uint32_t c = tab[0][i];
+        for (int s = 1; s < 4; s++) { c = tab[0][c & 0xFFu] ^ (c >> 8); tab[s][i] = c; }
+    }
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
+    for (uint32_t bi = blockIdx.x * waves + wave; bi < n_blocks; bi += gridDim.x * waves) {
+        const BgzfBlock b = blocks[bi];
+        if (b.status != INF_OK) continue;
+        const uint32_t isize = b.isize;
+        const uint32_t behind = (63u - lane) * CRC_CHUNK;                 // bytes after this lane's chunk
+        const uint32_t e = isize > behind ? isize - behind : 0u;          // chunk = [s, e)
+        const uint32_t s = e > CRC_CHUNK ? e - CRC_CHUNK : 0u;
+        uint32_t crc = (s == 0u && e > 0u) ? 0xFFFFFFFFu : 0u;
+        const uint8_t *p = out + b.out_off;
+        uint32_t i = s;
+        for (; i < e && ((uintptr_t)(p + i) & 3u); i++) crc = tab[0][(crc ^ p[i]) & 0xFFu] ^ (crc >> 8);
+        for (; i + 4u <= e; i += 4u) {
+            const uint32_t w = *(const uint32_t *)(p + i) ^ crc;
+            crc = tab[3][w & 0xFFu] ^ tab[2][(w >> 8) & 0xFFu] ^ tab[1][(w >> 16) & 0xFFu] ^ tab[0][w >> 24];
+        }
+        for (; i < e; i++) crc = tab[0][(crc ^ p[i]) & 0xFFu] ^ (crc >> 8);
+        if (behind && e > 0u) crc = gf2_mul(crc, xpow_kib[63u - lane]);
+        if (e == 0u) crc = 0u;
+        for (int o = 32; o >= 1; o >>= 1) crc ^= (uint32_t)__shfl_xor((int)crc, o);
+        if (lane == 0u) {
+            const uint32_t final_crc = isize ? ~crc : 0u;
+            if (final_crc != b.crc) blocks[bi].status = INF_BAD_CRC;
+        }
+    }
+}
+
+}  // namespace pssbam

@@ -1,0 +1,151 @@
+"""Device-side BGZF inflate (csrc/inflate_kernels.h): stored, fixed-Huffman and
+dynamic-Huffman deflate blocks inflated on the GPU must be byte-identical to zlib's output, the
+per-block ISIZE / CRC-32 check must pass on good input and flag damaged input, and nothing may
+fault on malformed streams.  Oracle: zlib (and, through the CRC in every BGZF trailer, the writer)."""
+import struct
+import zlib
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import __graft_entry__ as ge
+import pssbam_testlib as tl
+
+pytestmark = pytest.mark.gpu
+GOLD = Path(__file__).resolve().parent / "golden"
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    p = ge.load_pkg()
+    assert p.LIB_HIP.exists(), "libpssbam_hip.so missing: the HIP path must be built, there is no fallback"
+    return p
+
+
+def _bgzf(data: bytes, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, split=None) -> bytes:
+    """one BGZF block; split = (n, ...) emits several deflate blocks inside it (Z_FULL_FLUSH between)"""
+    co = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strategy)
+    if split:
+        parts, o = [], 0
+        for n in split:
+            parts.append(co.compress(data[o:o + n]) + co.flush(zlib.Z_FULL_FLUSH))
+            o += n
+        payload = b"".join(parts) + co.compress(data[o:]) + co.flush()
+    else:
+        payload = co.compress(data) + co.flush()
+    bsize = len(payload) + 25
+    assert bsize < 65536 + 26
+    return (b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", bsize) + payload
+            + struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data)))
+
+
+def _payloads(rng):
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    out = [b"", b"x", b"ab" * 3, bytes(rng.integers(0, 256, 1000, dtype=np.uint8)),            # tiny / incompressible
+           b"I" * 60000, b"abcdefg" * 9000, b"ab" * 30000, b"abc" * 21000, b"abcde" * 13000,     # distances 1..7
+           acgt[rng.integers(0, 4, 65280)].tobytes(), bytes(rng.integers(0, 256, 65280, dtype=np.uint8)),
+           bytes(rng.integers(0, 4, 65536, dtype=np.uint8)),                                     # a full 64 KiB block
+           ("@read%07d\tchr1\t%d\n" * 1).encode() * 1]
+    text = "".join(f"r{i:07d}\t{int(rng.integers(0, 1 << 20))}\tchr{int(rng.integers(1, 23))}\t{'I' * int(rng.integers(20, 150))}\n"
+                   for i in range(700)).encode()
+    out.append(text[:65000])
+    skew = rng.choice(np.arange(256, dtype=np.uint8), size=64000, p=np.r_[[0.5], np.full(255, 0.5 / 255)])
+    out.append(skew.tobytes())                                                                   # long and short codes
+    return out
+
+
+def test_stored_fixed_dynamic_blocks_match_zlib(pkg):
+    rng = np.random.default_rng(11)
+    blocks, want = [], []
+    for data in _payloads(rng):
+        for level, strategy, split in ((0, zlib.Z_DEFAULT_STRATEGY, None), (1, zlib.Z_DEFAULT_STRATEGY, None),
+                                       (6, zlib.Z_DEFAULT_STRATEGY, None), (9, zlib.Z_DEFAULT_STRATEGY, None),
+                                       (6, zlib.Z_FIXED, None), (6, zlib.Z_HUFFMAN_ONLY, None), (6, zlib.Z_RLE, None),
+                                       (6, zlib.Z_DEFAULT_STRATEGY, (len(data) // 3, len(data) // 3)),
+                                       (1, zlib.Z_FIXED, (len(data) // 2,))):
+            if level == 0 and len(data) > 65000:
+                continue     # a stored 64 KiB payload plus its framing exceeds the BGZF block size
+            blocks.append(_bgzf(data, level, strategy, split))
+            want.append(data)
+    # every deflate block type is really present
+    kinds = set()
+    for b in blocks:
+        if len(b) > 26:
+            kinds.add((b[18] >> 1) & 3)
+    assert kinds == {0, 1, 2}
+    buf = np.frombuffer(b"".join(blocks) + tl.BGZF_EOF, dtype=np.uint8)
+    res = pkg.bgzf_inflate(buf)
+    assert res["bad_block"] is None, f"block {res['bad_block']} failed with status {res['bad_status']}"
+    assert res["n_blocks"] == len(blocks) + 1
+    assert res["data"].tobytes() == b"".join(want)
+
+
+@pytest.mark.parametrize("name", ["setA.bam", "setB.bam"])
+def test_golden_bams_inflate_like_zlib(pkg, name):
+    raw = (GOLD / name).read_bytes()
+    res = pkg.bgzf_inflate(np.frombuffer(raw, dtype=np.uint8))
+    assert res["bad_block"] is None
+    assert res["data"].tobytes() == tl.bgzf_inflate(raw)
+
+
+def test_generated_bam_levels_and_layouts(pkg, tmp_path):
+    """the synthetic BAM writer's files (htslib layout and blocks cut regardless of records), levels
+    0 / 1 / 6: device output == zlib's, and the records index cleanly"""
+    from pss_bam_amd import synth
+    d = synth.config("C4", scale_genome=0.001, n_reads=150_000)
+    d.pop("region_len")
+    cfg = synth.make_cfg(**d)
+    ref = None
+    for level, ragged in ((1, False), (6, True), (0, False)):
+        bam = tmp_path / f"g{level}{int(ragged)}.bam"
+        synth.bam_file_host(cfg, 0, 150_000, bam, level=level, threads=4, ragged=ragged)
+        raw = bam.read_bytes()
+        res = pkg.bgzf_inflate(np.frombuffer(raw, dtype=np.uint8))
+        assert res["bad_block"] is None, (level, ragged, res["bad_block"], res["bad_status"])
+        got = res["data"].tobytes()
+        assert got == tl.bgzf_inflate(raw)
+        ref = ref or got
+        assert got == ref            # same records whatever the level / layout
+
+
+def test_damaged_blocks_are_flagged_not_followed(pkg):
+    rng = np.random.default_rng(5)
+    data = [("q%06d\t" % i).encode() * 40 + bytes(rng.integers(65, 70, 300, dtype=np.uint8)) for i in range(64)]
+    blocks = [_bgzf(d, 6) for d in data]
+    good = b"".join(blocks)
+    for trial in range(40):
+        k = int(rng.integers(0, len(blocks)))
+        bad = bytearray(blocks[k])
+        kind = trial % 4
+        if kind == 0:     # payload bit flip
+            o = int(rng.integers(18, len(bad) - 8))
+            bad[o] ^= 1 << int(rng.integers(0, 8))
+        elif kind == 1:   # CRC field
+            bad[-8] ^= 0x40
+        elif kind == 2:   # ISIZE too large (still <= 64 KiB)
+            struct.pack_into("<I", bad, len(bad) - 4, min(65536, len(data[k]) + int(rng.integers(1, 200))))
+        else:             # ISIZE too small
+            struct.pack_into("<I", bad, len(bad) - 4, max(0, len(data[k]) - int(rng.integers(1, 200))))
+        buf = b"".join(blocks[:k]) + bytes(bad) + b"".join(blocks[k + 1:])
+        res = pkg.bgzf_inflate(np.frombuffer(buf, dtype=np.uint8))
+        assert res["bad_block"] == k and res["bad_status"] != 0, (trial, kind, res["bad_block"], res["bad_status"])
+    res = pkg.bgzf_inflate(np.frombuffer(good, dtype=np.uint8))
+    assert res["bad_block"] is None and res["data"].tobytes() == b"".join(data)
+
+
+def test_hostile_streams_never_fault(pkg):
+    """random bytes dressed up as BGZF blocks: every block must come back flagged (or, by chance,
+    valid), and the call must return"""
+    rng = np.random.default_rng(99)
+    blocks = []
+    for i in range(256):
+        n = int(rng.integers(1, 3000))
+        payload = bytes(rng.integers(0, 256, n, dtype=np.uint8))
+        if i % 3 == 0:
+            payload = bytes([0b101]) + payload      # BFINAL + dynamic header, garbage behind it
+        isize = int(rng.integers(0, 65537))
+        blocks.append(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", len(payload) + 25) + payload
+                      + struct.pack("<II", int(rng.integers(0, 1 << 32)), isize))
+    res = pkg.bgzf_inflate(np.frombuffer(b"".join(blocks), dtype=np.uint8))
+    assert res["n_blocks"] == 256 and res["bad_block"] is not None
