@@ -32,6 +32,7 @@ extern "C" {
 #endif
 
 #define PSSBAM_ABI_VERSION 1
+#define PSSBAM_MAX_KLEN 15     /* 4^15 64-bit bins per k-mer table = 8.6 GB of device memory */
 
 /* error codes */
 #define PSSBAM_OK 0
@@ -65,7 +66,7 @@ typedef struct pssbam_pss_opts {
 
 /* fragkon's option globals, /root/reference/fragkon.c:14-18 (set by -k -l -L -q -m) */
 typedef struct pssbam_kmer_opts {
-    int32_t klen;              /* KLEN, 1..12 on the device                              */
+    int32_t klen;              /* KLEN, 1..PSSBAM_MAX_KLEN on the device                 */
     int32_t min_mq;
     uint64_t min_read_len;
     uint64_t max_read_len;
@@ -179,7 +180,7 @@ int pssbam_engine_bind_counters(pssbam_engine *e, void *d_counters, size_t n_u64
 
 /* genome-kmer-count (/root/reference/genome-kmer-count.c:56-79) on the uploaded genome: counts
  * every k-mer start of every contig (windows touching a non-ACGT base are not counted), k in
- * 1..12.  counts[4^k] in the same bin order as the fragkon tables.  Needs set_genome only. */
+ * 1..PSSBAM_MAX_KLEN.  counts[4^k] in the same bin order as the fragkon tables.  Needs set_genome only. */
 int pssbam_engine_genome_kmer_count(pssbam_engine *e, int klen, uint64_t *counts);
 
 /* Node-level sum for one process driving several GPUs (one engine per device): adds the

@@ -638,7 +638,7 @@ int orc_fk_run(const orc_genome *g, const char *sam_path, const orc_fk_params *p
                unsigned int *k3, unsigned long status[ORC_ST_N])
 {
     fk_ctx c = {g, p, k5, k3};
-    if (p->klen < 1 || p->klen > 14) return -2;
+    if (p->klen < 1 || p->klen > 15) return -2;
     return for_each_sam_line(sam_path, fk_line, &c, status);
 }
 
@@ -668,7 +668,7 @@ static int gkc_at(const void *ctx, long i) { return ((const unsigned char *)ctx)
 /* count_kmers, genome-kmer-count.c:69-79: add_to_ksp at every start i < len - k + 1 */
 int orc_genome_kmer_count(const orc_genome *g, int klen, unsigned int *counts)
 {
-    if (klen < 1 || klen > 14) return -2;
+    if (klen < 1 || klen > 15) return -2;
     for (size_t c = 0; c < g->n; c++) {
         const orc_contig *s = &g->contigs[c];
         if (s->len < (size_t)klen) continue;

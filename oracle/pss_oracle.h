@@ -93,7 +93,7 @@ typedef struct orc_fk_params {
 } orc_fk_params;
 
 /* k5 / k3: 4^klen unsigned int each (saturating, kmer.c:102-104), index = 2 bits per
- * base left-to-right, A0 C1 G2 T3 (kmer.c:184-214).  klen in [1,14].                */
+ * base left-to-right, A0 C1 G2 T3 (kmer.c:184-214).  klen in [1,15].                */
 int orc_fk_run(const orc_genome *g, const char *sam_path, const orc_fk_params *p,
                unsigned int *k5, unsigned int *k3, unsigned long status[ORC_ST_N]);
 int orc_fk_process(const orc_genome *g, const orc_fk_params *p, const orc_aln *a,

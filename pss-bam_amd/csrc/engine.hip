@@ -161,8 +161,10 @@ extern "C" int pssbam_engine_create(const pssbam_config *cfg, pssbam_engine **ou
             return fail(PSSBAM_EINVAL, "region_len %d out of range", cfg->pss.region_len);
         if (!cfg->pss.up_ctx || !cfg->pss.down_ctx) return fail(PSSBAM_EINVAL, "up_ctx/down_ctx must be set");
     }
-    if ((cfg->tally_mask & PSSBAM_TALLY_KMER) && (cfg->kmer.klen < 1 || cfg->kmer.klen > 12))
-        return fail(PSSBAM_EINVAL, "klen %d outside the device range 1..12", cfg->kmer.klen);
+    // 4^k 64-bit bins per table in device memory: k = 15 is 2 x 8.6 GB of the 288 GB (the reference's
+    // tree grows without bound, kmer.c:67-98; beyond 15 the bin index no longer fits the kernels' u32)
+    if ((cfg->tally_mask & PSSBAM_TALLY_KMER) && (cfg->kmer.klen < 1 || cfg->kmer.klen > PSSBAM_MAX_KLEN))
+        return fail(PSSBAM_EINVAL, "klen %d outside the device range 1..%d", cfg->kmer.klen, PSSBAM_MAX_KLEN);
 
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0)
@@ -784,7 +786,7 @@ extern "C" int pssbam_engine_counters_device(pssbam_engine *e, void **d_counters
 
 extern "C" int pssbam_engine_genome_kmer_count(pssbam_engine *e, int klen, uint64_t *counts) {
     if (!e || !counts) return fail(PSSBAM_EINVAL, "null argument");
-    if (klen < 1 || klen > 12) return fail(PSSBAM_EINVAL, "klen %d outside the device range 1..12", klen);
+    if (klen < 1 || klen > PSSBAM_MAX_KLEN) return fail(PSSBAM_EINVAL, "klen %d outside the device range 1..%d", klen, PSSBAM_MAX_KLEN);
     if (!e->d_genome) return fail(PSSBAM_ESTATE, "set_genome has not been called");
     HIP_TRY(hipSetDevice(e->device));
     const size_t nb = (size_t)1 << (2 * klen);

@@ -413,7 +413,7 @@ __device__ __forceinline__ void tally_tiled_body(const TallyParams &P, const Tal
             int64_t w5, w3;
             kmer_windows(pl, P.K, w5, w3);
             const uint64_t ka = pl.gbase + (uint64_t)(kwhich ? w3 : w5);
-            const Tri kq = *(const Tri *)(P.genome4 + (ka >> 3));  // 12 window nibbles at any alignment, one gather
+            const Tri kq = *(const Tri *)(P.genome4 + (ka >> 3));  // 15 window nibbles at any alignment (<= 22 of 24), one gather
 #pragma unroll
             for (int k = 0; k < 3; k++) kw[k] = kq.v[k];
             ksh = 4u * (uint32_t)(ka & 7ull);
@@ -536,7 +536,7 @@ __device__ __forceinline__ void tally_tiled_body(const TallyParams &P, const Tal
                 // reverse-strand read the window is reverse-complemented (fragkon.c:156-160)
                 uint32_t bin = 0u, bad = 0u;
 #pragma unroll
-                for (int t = 0; t < 12; t++) {
+                for (int t = 0; t < 16; t++) {   // K <= 15
                     if (t < P.K) {
                         const uint32_t c = (kw[t >> 3] >> (4 * (t & 7))) & 0xFu;
                         bad |= c & ~3u;
@@ -890,7 +890,7 @@ __device__ __forceinline__ void tally_compact_body(const TallyParams &P, const T
             if (kmer_try) {
                 uint32_t bin = 0u, bad = 0u;
 #pragma unroll
-                for (int t = 0; t < 12; t++) {
+                for (int t = 0; t < 16; t++) {   // K <= 15
                     if (t < P.K) {
                         const uint32_t c = (kw[t >> 3] >> (4 * (t & 7))) & 0xFu;
                         bad |= c & ~3u;

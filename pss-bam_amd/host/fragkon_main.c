@@ -3,7 +3,7 @@
  *
  * Same options, stderr banners and stdout table as the reference front end
  * (/root/reference/fragkon.c:253-386); the k-mer tallies come from the GPU engine's flat
- * 4^k histograms (k <= 12 on the device).  See pss_main.c for what differs underneath.
+ * 4^k histograms (k <= 15 on the device).  See pss_main.c for what differs underneath.
  */
 #include <ctype.h>
 #include <stdio.h>
@@ -58,8 +58,8 @@ int main(int argc, char *argv[])
               stderr);
         exit(1);
     }
-    if (klen < 1 || klen > 12) {
-        fprintf(stderr, "k-mer length %d is outside the range this build tallies on the GPU (1..12).\n", klen);
+    if (klen < 1 || klen > PSSBAM_MAX_KLEN) {
+        fprintf(stderr, "k-mer length %d is outside the range this build tallies on the GPU (1..%d).\n", klen, PSSBAM_MAX_KLEN);
         exit(1);
     }
 

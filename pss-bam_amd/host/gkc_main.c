@@ -1,7 +1,7 @@
 /*
  * pss-bam_amd/host/gkc_main.c -- the `genome-kmer-count` command, MI355X edition: same options
  * and stdout as the reference (/root/reference/genome-kmer-count.c:23-66); the 4^k histogram of
- * all k-mer starts is computed on the GPU from the uploaded genome (k <= 12).
+ * all k-mer starts is computed on the GPU from the uploaded genome (k <= 15).
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -37,8 +37,8 @@ int main(int argc, char *argv[])
         }
     }
     if (strlen(fa_in) == 0) help();
-    if (k < 1 || k > 12) {
-        fprintf(stderr, "k-mer length %d is outside the range this build counts on the GPU (1..12).\n", k);
+    if (k < 1 || k > PSSBAM_MAX_KLEN) {
+        fprintf(stderr, "k-mer length %d is outside the range this build counts on the GPU (1..%d).\n", k, PSSBAM_MAX_KLEN);
         return 1;
     }
     Genome *genome = init_genome(fa_in);

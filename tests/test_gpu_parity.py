@@ -226,7 +226,7 @@ def test_c_abi_error_conventions(pkg, tmp_path):
     with pytest.raises(pkg.PssbamError, match="tally_mask"):
         pkg.Engine()                                              # neither tally requested
     with pytest.raises(pkg.PssbamError, match="klen"):
-        pkg.Engine(kmer=dict(klen=13))
+        pkg.Engine(kmer=dict(klen=16))
     with pytest.raises(pkg.PssbamError, match="region_len"):
         pkg.Engine(pss=dict(region_len=-1))
     with pytest.raises(pkg.PssbamError, match="does not exist"):
@@ -256,3 +256,34 @@ def test_c_abi_error_conventions(pkg, tmp_path):
         assert eng.finish().stats["records"] == len(recs)
     finally:
         eng.close()
+
+
+def test_kmer_lengths_beyond_twelve(pkg, oracle, tmp_path):
+    """fragkon / genome-kmer-count accept any -k in the reference (fragkon.c:260, tree beyond 8 bases
+    kmer.c:67-98); the device keeps 4^k 64-bit bins per table in HBM up to k = 15 (2 x 8.6 GB).
+    k = 13 through both kernels and the genome census, k = 15 through the production kernel."""
+    contigs, refs, recs = tl.fuzz_dataset(1313, 3000, contig_lens=(60000, 9000, 1500))
+    fa, sam = tmp_path / "g.fa", tmp_path / "a.sam"
+    tl.write_fasta(fa, contigs)
+    tl.write_sam(sam, refs, recs)
+    raw = tl.raw_records(refs, recs)
+    g = oracle.load_genome(fa)
+    try:
+        for k, kernels in ((13, (pkg.KERNEL_SIMPLE, pkg.KERNEL_TILED)), (15, (pkg.KERNEL_TILED,))):
+            ko = tl.FkOpts(klen=k)
+            w5, w3, stk = oracle.fragkon(g, sam, ko)
+            assert int(w5.sum()) > 500
+            for kern in kernels:
+                got = _engine_tables(pkg, contigs, refs, raw, pss=dict(region_len=15), kmer=_fk_dict(ko), kernel=kern, chunks=2)
+                assert np.array_equal(got.k5, w5), f"5' k-mers differ at k={k}"
+                assert np.array_equal(got.k3, w3), f"3' k-mers differ at k={k}"
+                assert got.stats["kmer_ok"] == stk[tl.ST_OK] and got.stats["kmer_fail"] == stk[tl.ST_KMER_FAIL]
+                del got
+            del w5, w3
+        want = oracle.genome_kmer_count(g, 13)
+        eng = pkg.Engine(kmer=dict(klen=13))
+        eng.set_genome_arrays(tl.loaded_contigs(contigs))
+        assert np.array_equal(eng.genome_kmer_count(13), want)
+        eng.close()
+    finally:
+        oracle.free_genome(g)
