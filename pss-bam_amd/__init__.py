@@ -37,7 +37,8 @@ HIP_SYMBOLS = [
     "pssbam_engine_finish", "pssbam_engine_reset", "pssbam_engine_counters_device", "pssbam_engine_bind_counters",
     "pssbam_reduce_counters", "pssbam_engine_genome_kmer_count", "pssbam_host_register", "pssbam_host_unregister", "pssbam_engine_timer_begin",
     "pssbam_engine_timer_end", "pssbam_engine_kernel_time", "pssbam_index_records", "pssbam_bgzf_scan",
-    "pssbam_bgzf_inflate_device", "pssbam_bgzf_inflate_host",
+    "pssbam_bgzf_inflate_device", "pssbam_bgzf_inflate_host", "pssbam_engine_submit_bgzf", "pssbam_engine_wait_bgzf_copied",
+    "pssbam_engine_feed_status",
 ]
 
 
@@ -261,6 +262,57 @@ class Engine:
         a, b, c, d = C.c_double(), C.c_uint64(), C.c_double(), C.c_uint64()
         _chk(self._L.pssbam_engine_phase_times(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
         return {"h2d_ms": a.value, "h2d_bytes": b.value, "kernel_ms": c.value, "launches": d.value}
+
+    def submit_bgzf(self, bgzf: np.ndarray, header_bytes: int = 0, max_batch_inflated: int = 1 << 30) -> int:
+        """Whole BGZF blocks (host bytes) through the device-side feed: inflate, CRC, record index and
+        tally on the GPU.  header_bytes = inflated bytes in front of the first alignment record (the BAM
+        header when `bgzf` starts at the beginning of the file).  Returns the number of blocks."""
+        class _Blk(C.Structure):
+            _fields_ = [("in_off", C.c_uint64), ("in_len", C.c_uint32), ("isize", C.c_uint32), ("out_off", C.c_uint64),
+                        ("crc", C.c_uint32), ("status", C.c_uint32)]
+        L = self._L
+        L.pssbam_bgzf_scan.restype = C.c_int64
+        L.pssbam_bgzf_scan.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.pssbam_engine_submit_bgzf.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_uint32,
+                                                C.POINTER(C.c_uint64)]
+        L.pssbam_engine_wait_bgzf_copied.argtypes = [C.c_void_p, C.c_uint64]
+        bgzf = np.ascontiguousarray(bgzf, dtype=np.uint8)
+        consumed = C.c_uint64()
+        n = L.pssbam_bgzf_scan(bgzf.ctypes.data, bgzf.size, None, 0, C.byref(consumed), None)
+        if n < 0:
+            _chk(int(n))
+        if consumed.value != bgzf.size:
+            raise PssbamError("input ends inside a BGZF block")
+        blocks = (_Blk * max(int(n), 1))()
+        L.pssbam_bgzf_scan(bgzf.ctypes.data, bgzf.size, blocks, n, None, None)
+        i, skip = 0, header_bytes
+        while i < n and skip >= blocks[i].isize and (skip > 0 or blocks[i].isize == 0):   # blocks that are all header
+            skip -= blocks[i].isize
+            i += 1
+        while i < n:
+            j, base_in, base_out = i, blocks[i].in_off & ~3, blocks[i].out_off
+            while j < n and blocks[j].out_off + blocks[j].isize - base_out <= max_batch_inflated:
+                j += 1
+            j = max(j, i + 1)
+            grp = (_Blk * (j - i))()
+            for k in range(i, j):
+                grp[k - i] = blocks[k]
+                grp[k - i].in_off -= base_in
+                grp[k - i].out_off -= base_out
+            end_in = blocks[j - 1].in_off + blocks[j - 1].in_len
+            t = C.c_uint64()
+            _chk(L.pssbam_engine_submit_bgzf(self._h, bgzf.ctypes.data + base_in, end_in - base_in, grp, j - i, skip, C.byref(t)))
+            _chk(L.pssbam_engine_wait_bgzf_copied(self._h, t.value))
+            skip = 0
+            i = j
+        return int(n)
+
+    def feed_status(self) -> dict:
+        L = self._L
+        L.pssbam_engine_feed_status.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+        f, ms, nb = C.c_uint32(), C.c_double(), C.c_uint64()
+        _chk(L.pssbam_engine_feed_status(self._h, C.byref(f), C.byref(ms), C.byref(nb)))
+        return {"flags": int(f.value), "inflate_ms": float(ms.value), "inflated_bytes": int(nb.value)}
 
     def submit_device(self, d_records: int, nbytes: int, d_offsets: int, n_records: int):
         _chk(self._L.pssbam_engine_submit_device(self._h, C.c_void_p(d_records), nbytes, C.c_void_p(d_offsets),

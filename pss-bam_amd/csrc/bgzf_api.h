@@ -169,3 +169,139 @@ extern "C" int pssbam_bgzf_inflate_host(int device, const void *bgzf, uint64_t n
     cleanup();
     return PSSBAM_OK;
 }
+
+// --------------------------------------------------------------------------------------
+// the feed: compressed batch -> device inflate -> device record index -> tally, one call
+// --------------------------------------------------------------------------------------
+template <class T>
+static int grow(T **ptr, size_t *cap, size_t need, size_t elem = sizeof(T)) {
+    if (*cap >= need) return PSSBAM_OK;
+    if (*ptr) HIP_TRY(hipFree(*ptr));
+    *ptr = nullptr;
+    *cap = need + need / 8 + 4096;
+    HIP_TRY(hipMalloc((void **)ptr, *cap * elem));
+    return PSSBAM_OK;
+}
+
+extern "C" int pssbam_engine_submit_bgzf(pssbam_engine *e, const void *comp, uint64_t comp_bytes, const pssbam_bgzf_block *blocks,
+                                         uint32_t n_blocks, uint32_t first_record_offset, uint64_t *ticket) {
+    int rc = check_ready(e);
+    if (rc) return rc;
+    if (ticket) *ticket = 0;
+    if (!n_blocks) return PSSBAM_OK;
+    if (!comp || !blocks) return fail(PSSBAM_EINVAL, "null buffer");
+    const uint64_t out_bytes = blocks[n_blocks - 1].out_off + blocks[n_blocks - 1].isize;
+    if (out_bytes >= (1ull << 32) - (1ull << 16)) return fail(PSSBAM_EINVAL, "batch inflates to %llu bytes; keep batches below 4 GiB", (unsigned long long)out_bytes);
+    if (blocks[0].out_off != 0) return fail(PSSBAM_EINVAL, "blocks[0].out_off must be 0");
+    if (first_record_offset > blocks[0].isize) return fail(PSSBAM_EINVAL, "first_record_offset lies beyond the first block");
+    HIP_TRY(hipSetDevice(e->device));
+    if (!e->d_feed_flags) {
+        HIP_TRY(hipMalloc(&e->d_feed_flags, sizeof(uint32_t)));
+        HIP_TRY(hipMemsetAsync(e->d_feed_flags, 0, sizeof(uint32_t), e->stream));
+    }
+    FeedSlot &s = e->feed[e->next_feed];
+    e->next_feed ^= 1;
+    if (!s.copied) {
+        HIP_TRY(hipEventCreate(&s.copy_begin));
+        HIP_TRY(hipEventCreate(&s.copied));
+        HIP_TRY(hipEventCreateWithFlags(&s.consumed, hipEventDisableTiming));
+    }
+    if (s.busy) HIP_TRY(hipEventSynchronize(s.consumed));
+    s.busy = false;
+    if (s.timed) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, s.copy_begin, s.copied) == hipSuccess) e->h2d_ms += ms;
+        s.timed = false;
+    }
+    const uint64_t max_recs = out_bytes / 36ull + 2ull;   // a record is at least 36 bytes
+    size_t bc = s.blocks_cap, bc2 = s.blocks_cap, bc3 = s.blocks_cap;
+    if ((rc = grow(&s.d_comp, &s.comp_cap, (size_t)comp_bytes + 16))) return rc;
+    if ((rc = grow((uint8_t **)&s.d_blocks, &bc, (size_t)n_blocks, sizeof(pssbam::BgzfBlock)))) return rc;
+    if ((rc = grow(&s.d_counts, &bc2, (size_t)n_blocks))) return rc;
+    if ((rc = grow(&s.d_base, &bc3, (size_t)n_blocks))) return rc;
+    s.blocks_cap = std::min(bc, std::min(bc2, bc3));
+    if ((rc = grow(&s.d_out, &s.out_cap, (size_t)out_bytes + 64))) return rc;
+    if ((rc = grow(&s.d_offs, &s.offs_cap, (size_t)max_recs))) return rc;
+    if (!s.d_nrecs) HIP_TRY(hipMalloc(&s.d_nrecs, sizeof(uint32_t)));
+
+    // compressed bytes + block table over PCIe (two copy streams for large batches, like submit)
+    HIP_TRY(hipEventRecord(s.copy_begin, e->copy_stream));
+    const uint64_t half = comp_bytes >= (32ull << 20) ? (comp_bytes / 2) & ~4095ull : 0;
+    if (half) {
+        HIP_TRY(hipStreamWaitEvent(e->copy_stream2, s.copy_begin, 0));
+        HIP_TRY(hipMemcpyAsync(s.d_comp + half, (const uint8_t *)comp + half, comp_bytes - half, hipMemcpyHostToDevice, e->copy_stream2));
+        HIP_TRY(hipEventRecord(e->copied2, e->copy_stream2));
+    }
+    HIP_TRY(hipMemcpyAsync(s.d_comp, comp, half ? half : comp_bytes, hipMemcpyHostToDevice, e->copy_stream));
+    HIP_TRY(hipMemcpyAsync(s.d_blocks, blocks, (size_t)n_blocks * sizeof(pssbam_bgzf_block), hipMemcpyHostToDevice, e->copy_stream));
+    if (half) HIP_TRY(hipStreamWaitEvent(e->copy_stream, e->copied2, 0));
+    HIP_TRY(hipEventRecord(s.copied, e->copy_stream));
+    s.timed = true;
+    e->h2d_bytes += comp_bytes + (uint64_t)n_blocks * sizeof(pssbam_bgzf_block);
+    HIP_TRY(hipStreamWaitEvent(e->stream, s.copied, 0));
+
+    // inflate + CRC + record index on the engine's stream
+    hipEvent_t ev0 = take_event(e), ev1 = take_event(e);
+    if (!ev0 || !ev1) return fail(PSSBAM_EHIP, "hipEventCreate failed");
+    HIP_TRY(hipEventRecord(ev0, e->stream));
+    rc = pssbam_bgzf_inflate_device(e->stream, s.d_comp, comp_bytes, (pssbam_bgzf_block *)s.d_blocks, n_blocks, s.d_out,
+                                    getenv("PSSBAM_NO_CRC") ? 0 : 1);
+    if (rc) return rc;
+    const uint32_t igrid = std::min<uint32_t>((n_blocks + 255u) / 256u, (uint32_t)e->n_cu * 8u);
+    hipLaunchKernelGGL(pssbam::bgzf_index_count, dim3(igrid), dim3(256), 0, e->stream, (const uint8_t *)s.d_out,
+                       (const pssbam::BgzfBlock *)s.d_blocks, n_blocks, first_record_offset, s.d_counts, e->d_feed_flags);
+    hipLaunchKernelGGL(pssbam::bgzf_index_scan, dim3(1), dim3(1024), 0, e->stream, (const uint32_t *)s.d_counts, n_blocks, s.d_base, s.d_nrecs);
+    hipLaunchKernelGGL(pssbam::bgzf_index_write, dim3(igrid), dim3(256), 0, e->stream, (const uint8_t *)s.d_out,
+                       (const pssbam::BgzfBlock *)s.d_blocks, n_blocks, first_record_offset, (const uint32_t *)s.d_counts,
+                       (const uint32_t *)s.d_base, s.d_offs, (const uint32_t *)s.d_nrecs, (uint32_t)out_bytes);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ev1, e->stream));
+    e->inflate_events.emplace_back(ev0, ev1);
+    e->inflated_bytes += out_bytes;
+
+    rc = launch_tally(e, s.d_out, out_bytes, s.d_offs, (uint32_t)std::min<uint64_t>(max_recs, 0xFFFFFFF0ull), nullptr, 0, s.d_nrecs,
+                      first_record_offset);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(s.consumed, e->stream));
+    s.busy = true;
+    s.ticket = ++e->ticket_seq;
+    if (ticket) *ticket = s.ticket;
+    return PSSBAM_OK;
+}
+
+// copy completion of a submit_bgzf ticket (the compressed staging buffer is then free)
+extern "C" int pssbam_engine_wait_bgzf_copied(pssbam_engine *e, uint64_t ticket) {
+    if (!e) return fail(PSSBAM_EINVAL, "null engine");
+    if (!ticket) return PSSBAM_OK;
+    for (FeedSlot &s : e->feed)
+        if (s.ticket == ticket) {
+            HIP_TRY(hipSetDevice(e->device));
+            HIP_TRY(hipEventSynchronize(s.copied));
+            return PSSBAM_OK;
+        }
+    return PSSBAM_OK;
+}
+
+// Drains the engine and reports what the device-side feed saw: *flags = OR of 1 (a block failed
+// inflate / ISIZE / CRC-32), 2 (records cross BGZF blocks: the device index cannot be used, fall
+// back to the host reader), 4 (a record length below 32); inflate_ms / inflated_bytes = summed
+// inflate + CRC + index kernel time and payload.
+extern "C" int pssbam_engine_feed_status(pssbam_engine *e, uint32_t *flags, double *inflate_ms, uint64_t *inflated_bytes) {
+    if (!e) return fail(PSSBAM_EINVAL, "null engine");
+    int rc = pssbam_engine_sync(e);
+    if (rc) return rc;
+    uint32_t f = 0;
+    if (e->d_feed_flags) HIP_TRY(hipMemcpy(&f, e->d_feed_flags, sizeof f, hipMemcpyDeviceToHost));
+    for (auto &p : e->inflate_events) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, p.first, p.second));
+        e->inflate_ms += ms;
+        e->event_pool.push_back(p.first);
+        e->event_pool.push_back(p.second);
+    }
+    e->inflate_events.clear();
+    if (flags) *flags = f;
+    if (inflate_ms) *inflate_ms = e->inflate_ms;
+    if (inflated_bytes) *inflated_bytes = e->inflated_bytes;
+    return PSSBAM_OK;
+}

@@ -77,6 +77,22 @@ struct Slot {  // one in-flight host-submitted block
     uint64_t ticket = 0;      // the submit that last used the slot
 };
 
+struct FeedSlot {  // one in-flight compressed batch (pssbam_engine_submit_bgzf)
+    uint8_t *d_comp = nullptr;
+    size_t comp_cap = 0;
+    void *d_blocks = nullptr;       // pssbam::BgzfBlock[]
+    uint32_t *d_counts = nullptr, *d_base = nullptr;
+    size_t blocks_cap = 0;
+    uint8_t *d_out = nullptr;
+    size_t out_cap = 0;
+    uint32_t *d_offs = nullptr;
+    size_t offs_cap = 0;
+    uint32_t *d_nrecs = nullptr;
+    hipEvent_t copy_begin = nullptr, copied = nullptr, consumed = nullptr;
+    bool busy = false, timed = false;
+    uint64_t ticket = 0;
+};
+
 struct pssbam_engine {
     pssbam_config cfg{};
     std::string up_ctx, down_ctx, rg;
@@ -114,6 +130,13 @@ struct pssbam_engine {
     uint64_t ticket_seq = 0;
     double h2d_ms = 0.0;      // summed H2D copy durations (events on the copy stream)
     uint64_t h2d_bytes = 0;
+    // device-side inflate feed
+    FeedSlot feed[2];
+    int next_feed = 0;
+    uint32_t *d_feed_flags = nullptr;
+    double inflate_ms = 0.0;  // summed inflate + CRC + index kernel durations
+    uint64_t inflated_bytes = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> inflate_events;
     // timing
     hipEvent_t t_begin = nullptr, t_end = nullptr;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> launch_events;
@@ -243,6 +266,20 @@ extern "C" void pssbam_engine_destroy(pssbam_engine *e) {
         if (s.copy_begin) (void)hipEventDestroy(s.copy_begin);
         if (s.consumed) (void)hipEventDestroy(s.consumed);
     }
+    for (FeedSlot &s : e->feed) {
+        if (s.d_comp) (void)hipFree(s.d_comp);
+        if (s.d_blocks) (void)hipFree(s.d_blocks);
+        if (s.d_counts) (void)hipFree(s.d_counts);
+        if (s.d_base) (void)hipFree(s.d_base);
+        if (s.d_out) (void)hipFree(s.d_out);
+        if (s.d_offs) (void)hipFree(s.d_offs);
+        if (s.d_nrecs) (void)hipFree(s.d_nrecs);
+        if (s.copy_begin) (void)hipEventDestroy(s.copy_begin);
+        if (s.copied) (void)hipEventDestroy(s.copied);
+        if (s.consumed) (void)hipEventDestroy(s.consumed);
+    }
+    if (e->d_feed_flags) (void)hipFree(e->d_feed_flags);
+    for (auto &p : e->inflate_events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (auto &p : e->launch_events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (hipEvent_t ev : e->event_pool) (void)hipEventDestroy(ev);
     if (e->t_begin) (void)hipEventDestroy(e->t_begin);
@@ -454,14 +491,19 @@ static uint32_t sample_prefix_pieces(const uint8_t *bytes, uint64_t nbytes, bool
     return (uint32_t)std::min<uint64_t>(std::max<uint64_t>(pieces, 5), 41);
 }
 
+// d_n_recs != NULL: the record count lives in device memory (blocks indexed on the device); n_records
+// is then only an upper bound for the launch geometry, and the prefix sample is taken sample_off
+// bytes into the block.
 static int launch_tally(pssbam_engine *e, const uint8_t *d_recs, uint64_t nbytes, const uint32_t *d_offs,
-                        uint32_t n_records, const uint8_t *host_sample, uint64_t host_sample_bytes) {
+                        uint32_t n_records, const uint8_t *host_sample, uint64_t host_sample_bytes,
+                        const uint32_t *d_n_recs = nullptr, uint64_t sample_off = 0) {
     if (!n_records) return PSSBAM_OK;
     const pssbam_config &c = e->cfg;
     TallyParams P{};
     P.recs = d_recs;
     P.offs = d_offs;
     P.n_recs = n_records;
+    P.n_recs_dev = d_n_recs;
     P.recs_bytes = nbytes;
     P.tally_mask = c.tally_mask;
     P.genome = e->d_genome;
@@ -497,6 +539,7 @@ static int launch_tally(pssbam_engine *e, const uint8_t *d_recs, uint64_t nbytes
     P.off_stats = e->off_stats;
 
     int kernel = c.kernel;
+    if (d_n_recs && kernel == PSSBAM_KERNEL_SIMPLE) return fail(PSSBAM_EINVAL, "device-indexed blocks need the tiled kernels");
     // the tiled kernel covers 32 table rows per pass over the block (measured on C3: N=30 18 G
     // reads/s, N=62 9.3 G, N=100 4.8 G; the generic kernel: 0.77 / 0.37 / 0.23 G and falling with
     // N), so it is the automatic choice for every N; the generic kernel is the cross-check
@@ -523,9 +566,10 @@ static int launch_tally(pssbam_engine *e, const uint8_t *d_recs, uint64_t nbytes
         if (host_sample) {
             pieces = sample_prefix_pieces(host_sample, host_sample_bytes, e->has_rg);
         } else {
-            if (!e->dev_pieces || avg * 8 < e->dev_pieces_avg * 7 || avg * 7 > e->dev_pieces_avg * 8) {
-                std::vector<uint8_t> head((size_t)std::min<uint64_t>(nbytes, 1024 * 1024));
-                HIP_TRY(hipMemcpyAsync(head.data(), d_recs, head.size(), hipMemcpyDeviceToHost, e->stream));
+            if (!e->dev_pieces || (!d_n_recs && (avg * 8 < e->dev_pieces_avg * 7 || avg * 7 > e->dev_pieces_avg * 8))) {
+                sample_off = std::min<uint64_t>(sample_off, nbytes);
+                std::vector<uint8_t> head((size_t)std::min<uint64_t>(nbytes - sample_off, 1024 * 1024));
+                HIP_TRY(hipMemcpyAsync(head.data(), d_recs + sample_off, head.size(), hipMemcpyDeviceToHost, e->stream));
                 HIP_TRY(hipStreamSynchronize(e->stream));
                 e->dev_pieces = sample_prefix_pieces(head.data(), head.size(), e->has_rg);
                 e->dev_pieces_avg = avg;

@@ -435,4 +435,81 @@ __global__ void __launch_bounds__(256) bgzf_crc_kernel(const uint8_t *out, BgzfB
     }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// record index of an inflated batch, on the device
+// ---------------------------------------------------------------------------------------
+// The tally kernels want a u32 offset per alignment record.  In files written by htslib every
+// BGZF block starts on a record boundary (bgzf_flush_try before a record that would not fit), so
+// the block_size chains of the blocks are independent: a lane per block counts its records, a
+// scan turns the counts into bases, a second walk writes the offsets.  A block whose chain does
+// not end exactly at its ISIZE (htsjdk-style layout, or a record larger than a block) raises
+// FEED_RAGGED and the caller falls back to the host reader, whose indexer follows the chain
+// across blocks.
+enum : uint32_t { FEED_BAD_BLOCK = 1u, FEED_RAGGED = 2u, FEED_BAD_RECORD = 4u };
+
+__device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t *p) {
+    uint32_t v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+}
+
+__global__ void __launch_bounds__(256) bgzf_index_count(const uint8_t *out, const BgzfBlock *blocks, uint32_t n_blocks,
+                                                        uint32_t first_off, uint32_t *counts, uint32_t *flags) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_blocks; i += gridDim.x * blockDim.x) {
+        const BgzfBlock b = blocks[i];
+        uint32_t n = 0u;
+        if (b.status != INF_OK) atomicOr(flags, FEED_BAD_BLOCK);
+        else {
+            const uint8_t *p = out + b.out_off;
+            uint32_t o = i == 0u ? first_off : 0u;
+            while (o + 4u <= b.isize) {
+                const uint32_t bs = load_u32_unaligned(p + o);
+                if (bs < 32u) { atomicOr(flags, FEED_BAD_RECORD); o = b.isize; break; }
+                if (bs > b.isize - o - 4u) break;   // runs past the block
+                o += 4u + bs;
+                n++;
+            }
+            if (o != b.isize) atomicOr(flags, FEED_RAGGED);
+        }
+        counts[i] = n;
+    }
+}
+
+// exclusive scan of up to a few hundred thousand counts by one workgroup; *total = their sum
+__global__ void __launch_bounds__(1024) bgzf_index_scan(const uint32_t *counts, uint32_t n, uint32_t *base, uint32_t *total) {
+    __shared__ uint32_t part[1024];
+    const uint32_t t = threadIdx.x, per = (n + 1023u) / 1024u;
+    const uint32_t lo = min(n, t * per), hi = min(n, lo + per);
+    uint32_t sum = 0u;
+    for (uint32_t i = lo; i < hi; i++) sum += counts[i];
+    part[t] = sum;
+    __syncthreads();
+    for (uint32_t d = 1u; d < 1024u; d <<= 1) {
+        const uint32_t v = t >= d ? part[t - d] : 0u;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[t] - sum;   // exclusive
+    for (uint32_t i = lo; i < hi; i++) { base[i] = run; run += counts[i]; }
+    if (t == 1023u) *total = part[1023];
+}
+
+__global__ void __launch_bounds__(256) bgzf_index_write(const uint8_t *out, const BgzfBlock *blocks, uint32_t n_blocks,
+                                                        uint32_t first_off, const uint32_t *counts, const uint32_t *base,
+                                                        uint32_t *offs, const uint32_t *total, uint32_t batch_bytes) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_blocks; i += gridDim.x * blockDim.x) {
+        const BgzfBlock b = blocks[i];
+        const uint8_t *p = out + b.out_off;
+        uint32_t o = i == 0u ? first_off : 0u, k = base[i];
+        const uint32_t k_end = k + counts[i];
+        while (k < k_end) {   // the same walk as bgzf_index_count, bounded by its count
+            offs[k++] = (uint32_t)b.out_off + o;
+            o += 4u + load_u32_unaligned(p + o);
+        }
+        if (i == n_blocks - 1u) offs[*total] = batch_bytes;
+    }
+}
+
 }  // namespace pssbam

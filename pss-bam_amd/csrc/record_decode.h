@@ -30,6 +30,7 @@ struct TallyParams {
     const uint8_t *recs;          // record block
     const uint32_t *offs;         // n_recs + 1 offsets into recs
     uint32_t n_recs;
+    const uint32_t *n_recs_dev;   // non-NULL: the record count is read from device memory (blocks indexed on the device)
     uint64_t recs_bytes;          // bytes of the record block (= offs[n_recs])
     uint32_t tally_mask;          // PSSBAM_TALLY_*
     const uint8_t *genome;        // all contigs, 1 stored byte/base (enc_byte), padded between

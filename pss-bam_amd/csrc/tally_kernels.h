@@ -272,6 +272,7 @@ __device__ __forceinline__ void tally_tiled_body(const TallyParams &P, const Tal
                                                  uint32_t *__restrict__ lds_kmer,
                                                  int32_t *__restrict__ lds_delta, uint4 *__restrict__ refs_lds) {
     const uint32_t T = P.reads_per_tile;   // <= TILED_MAX_T
+    const uint32_t n_recs = P.n_recs_dev ? *P.n_recs_dev : P.n_recs;   // device-indexed blocks: the count lives in device memory
     const uint32_t pieces = P.prefix_pieces;  // 16-byte pieces staged per record
     const uint64_t recs_limit = (P.recs_bytes + 15ull) & ~15ull;  // the block is readable up to here
     const uint32_t ablate = P.ablate;      // diagnostics only (PSSBAM_ABLATE): 1 no COLUMNS, 2 no position loop, 4 no CODES, 128 no window gathers
@@ -296,7 +297,7 @@ __device__ __forceinline__ void tally_tiled_body(const TallyParams &P, const Tal
     const uint32_t n_ref_cached = min((uint32_t)P.n_ref, REF_LDS_ENTRIES);
     if (tid < n_ref_cached) refs_lds[tid] = P.ref_info[tid];
     if (tid == n_ref_cached) refs_lds[tid] = P.ref_info[P.n_ref];
-    const uint32_t all_tiles = (P.n_recs + T - 1u) / T;
+    const uint32_t all_tiles = (n_recs + T - 1u) / T;
     // Workgroup -> tiles.  Workgroups are dealt to the 8 XCDs round-robin (blockIdx & 7); with
     // xcd_map every XCD walks its own contiguous eighth of the block, so neighbouring tiles -- which
     // share reference lines and the record line at their seam -- meet in the same L2.
@@ -317,9 +318,9 @@ __device__ __forceinline__ void tally_tiled_body(const TallyParams &P, const Tal
     const uint32_t TOFF = TILED_MAX_T + 4u;  // stride between the two offset buffers
     auto load_offsets = [&](uint32_t t) {
         const uint32_t r0 = t * T;
-        if (tid <= T && r0 + tid <= P.n_recs) off_a = P.offs[r0 + tid];
+        if (tid <= T && r0 + tid <= n_recs) off_a = P.offs[r0 + tid];
     };
-    auto tile_count = [&](uint32_t t) { return min(T, P.n_recs - t * T); };
+    auto tile_count = [&](uint32_t t) { return min(T, n_recs - t * T); };
     __syncthreads();  // LDS tables are set up
     if (tile < n_tiles) {
         load_offsets(tile);
@@ -333,7 +334,7 @@ __device__ __forceinline__ void tally_tiled_body(const TallyParams &P, const Tal
         const uint32_t par = it & 1u;
         const uint32_t *cur_offs = toffs + par * TOFF;
         const uint32_t r0 = tile * T;
-        const uint32_t count = min(T, P.n_recs - r0);
+        const uint32_t count = min(T, n_recs - r0);
         const uint32_t next = tile + tstride;
 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // DMA pieces + offset loads of this wave are in
@@ -680,6 +681,7 @@ __device__ __forceinline__ void tally_compact_body(const TallyParams &P, const T
                                                    uint4 *__restrict__ refs_lds, uint32_t *__restrict__ ctx_rep,
                                                    uint32_t *__restrict__ ovf_list, uint32_t *__restrict__ ovf_n) {
     const uint32_t T = P.reads_per_tile;
+    const uint32_t n_recs = P.n_recs_dev ? *P.n_recs_dev : P.n_recs;   // device-indexed blocks: the count lives in device memory
     const uint32_t pieces = P.prefix_pieces;
     const uint32_t recs_limit32 = (uint32_t)(((P.recs_bytes + 15ull) & ~15ull) - 16ull);  // last piece start that is readable
     const uint32_t tid = threadIdx.x;
@@ -706,16 +708,16 @@ __device__ __forceinline__ void tally_compact_body(const TallyParams &P, const T
     const uint32_t n_ref_cached = min((uint32_t)P.n_ref, REF_LDS_ENTRIES);
     if (tid < n_ref_cached) refs_lds[tid] = P.ref_info[tid];
     if (tid == n_ref_cached) refs_lds[tid] = P.ref_info[P.n_ref];
-    const uint32_t all_tiles = (P.n_recs + T - 1u) / T;
+    const uint32_t all_tiles = (n_recs + T - 1u) / T;
     uint32_t tile = blockIdx.x;
     const uint32_t tstride = gridDim.x, n_tiles = all_tiles;
     uint32_t off_a = 0;
     const uint32_t TOFF = TILED_MAX_T + 4u;
     auto load_offsets = [&](uint32_t t) {
         const uint32_t r0 = t * T;
-        if (tid <= T && r0 + tid <= P.n_recs) off_a = P.offs[r0 + tid];
+        if (tid <= T && r0 + tid <= n_recs) off_a = P.offs[r0 + tid];
     };
-    auto tile_count = [&](uint32_t t) { return min(T, P.n_recs - t * T); };
+    auto tile_count = [&](uint32_t t) { return min(T, n_recs - t * T); };
     __syncthreads();
     if (tile < n_tiles) {
         load_offsets(tile);
@@ -729,7 +731,7 @@ __device__ __forceinline__ void tally_compact_body(const TallyParams &P, const T
         const uint32_t par = it & 1u;
         const uint32_t *cur_offs = toffs + par * TOFF;
         const uint32_t r0 = tile * T;
-        const uint32_t count = min(T, P.n_recs - r0);
+        const uint32_t count = min(T, n_recs - r0);
         const uint32_t next = tile + tstride;
 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1027,7 +1029,7 @@ __global__ void __launch_bounds__(256) reduce_partials(const TallyParams P, uint
     if (is_delta && g == 0u) {
         // every launch credits its record count to the OK slots; the deltas move records elsewhere
         const uint32_t k = i - SCRATCH_DELTA;
-        if (k == ST_RECORDS || (do_pss && k == ST_PSS_OK) || (do_kmer && k == ST_KMER_OK)) sum += P.n_recs;
+        if (k == ST_RECORDS || (do_pss && k == ST_PSS_OK) || (do_kmer && k == ST_KMER_OK)) sum += P.n_recs_dev ? *P.n_recs_dev : P.n_recs;
     }
     if (sum) atomicAdd(dst, (unsigned long long)sum);
 }

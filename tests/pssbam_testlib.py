@@ -435,6 +435,33 @@ def write_bam(path: Path, refs: list[tuple[str, int]], recs: list[Rec], level: i
         fh.write(BGZF_EOF)
 
 
+def write_bam_aligned(path: Path, refs: list[tuple[str, int]], recs: list[Rec], level: int = 6, block: int = 0xFF00,
+                      rng: np.random.Generator | None = None) -> int:
+    """BGZF BAM in htslib's layout: the header in its own block(s), every later block holding whole
+    records only (a block is flushed before a record that would not fit; with `rng` at random fill
+    levels).  Returns the number of header bytes in the inflated stream."""
+    head = bam_bytes(refs, [])
+    idx = {n: i for i, (n, _) in enumerate(refs)}
+    with open(path, "wb") as fh:
+        for i in range(0, len(head), block):
+            fh.write(bgzf_block(head[i:i + block], level))
+        cur, limit = [], block if rng is None else int(rng.integers(300, block + 1))
+        size = 0
+        for r in recs:
+            b = bam_record(r, idx)
+            assert len(b) <= block
+            if size + len(b) > limit and cur:
+                fh.write(bgzf_block(b"".join(cur), level))
+                cur, size = [], 0
+                limit = block if rng is None else int(rng.integers(300, block + 1))
+            cur.append(b)
+            size += len(b)
+        if cur:
+            fh.write(bgzf_block(b"".join(cur), level))
+        fh.write(BGZF_EOF)
+    return len(head)
+
+
 # ----------------------------------------------------------------------------------
 # FASTA
 # ----------------------------------------------------------------------------------

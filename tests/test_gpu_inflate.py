@@ -149,3 +149,84 @@ def test_hostile_streams_never_fault(pkg):
                       + struct.pack("<II", int(rng.integers(0, 1 << 32)), isize))
     res = pkg.bgzf_inflate(np.frombuffer(b"".join(blocks), dtype=np.uint8))
     assert res["n_blocks"] == 256 and res["bad_block"] is not None
+
+
+def _bam_header_bytes(raw: bytes) -> int:
+    """inflated bytes in front of the first alignment record"""
+    data = tl.bgzf_inflate(raw)
+    l_text = struct.unpack_from("<i", data, 4)[0]
+    o = 8 + l_text
+    n_ref = struct.unpack_from("<i", data, o)[0]
+    o += 4
+    for _ in range(n_ref):
+        l_name = struct.unpack_from("<i", data, o)[0]
+        o += 4 + l_name + 4
+    return o
+
+
+def _contigs_of(fa_path):
+    fa_txt = Path(fa_path).read_text()
+    return [(blk.split("\n", 1)[0].split()[0], "".join(blk.split("\n")[1:])) for blk in fa_txt.split(">")[1:]]
+
+
+@pytest.mark.parametrize("seed,with_rg", [(41, False), (42, True)])
+def test_feed_compressed_bam_to_tables(pkg, tmp_path, seed, with_rg):
+    """submit_bgzf (copy compressed, inflate + CRC + record index + tally on the device) gives the same
+    tables and status tallies as the host path fed the inflated records, for every kernel variant the
+    device feed can use (N <= 16: tally_compact, N > 16: tally_tiled, k-mer tally fused, -R)"""
+    contigs, refs, recs = tl.fuzz_dataset(seed, 4000, with_rg=with_rg)
+    bam = tmp_path / "aligned.bam"
+    hb = tl.write_bam_aligned(bam, refs, recs, level=1 + seed % 6, rng=np.random.default_rng(seed))
+    raw = bam.read_bytes()
+    assert hb == _bam_header_bytes(raw)
+    rec_bytes = tl.raw_records(refs, recs)
+    for pss, kmer, rg in ((dict(region_len=15), None, None), (dict(region_len=25, min_mq=10), dict(klen=4), None),
+                          (dict(region_len=40), dict(klen=7), "grpA" if with_rg else None)):
+        want = None
+        for mode in ("host", "bgzf", "bgzf_small_batches"):
+            eng = pkg.Engine(pss=pss, kmer=kmer, read_group=rg)
+            eng.set_genome_arrays(tl.loaded_contigs(contigs))
+            eng.set_references([n for n, _ in refs])
+            if mode == "host":
+                eng.submit(rec_bytes)
+            else:
+                eng.submit_bgzf(np.frombuffer(raw, dtype=np.uint8), header_bytes=hb,
+                                max_batch_inflated=(1 << 30) if mode == "bgzf" else 70000)
+                assert eng.feed_status()["flags"] == 0
+            got = eng.finish()
+            eng.close()
+            if want is None:
+                want = got
+                assert got.stats["records"] == len(recs)
+            else:
+                assert np.array_equal(got.fwd, want.fwd) and np.array_equal(got.rev, want.rev), mode
+                if kmer:
+                    assert np.array_equal(got.k5, want.k5) and np.array_equal(got.k3, want.k3), mode
+                st_g, st_w = dict(got.stats), dict(want.stats)
+                st_g.pop("slow_path"), st_w.pop("slow_path")
+                assert st_g == st_w, (mode, got.stats, want.stats)
+
+
+def test_feed_flags_ragged_layout_and_damage(pkg, tmp_path):
+    """records crossing BGZF blocks raise PSSBAM_FEED_RAGGED (the caller then uses the host reader); a
+    damaged block raises PSSBAM_FEED_BAD_BLOCK"""
+    contigs, refs, recs = tl.fuzz_dataset(31, 3000)
+    bam = tmp_path / "ragged.bam"
+    tl.write_bam(bam, refs, recs, level=1, rng=np.random.default_rng(3), block=5000)
+    raw = bam.read_bytes()
+    eng = pkg.Engine(pss=dict(region_len=15))
+    eng.set_genome_arrays(tl.loaded_contigs(contigs))
+    eng.set_references([n for n, _ in refs])
+    eng.submit_bgzf(np.frombuffer(raw, dtype=np.uint8), header_bytes=_bam_header_bytes(raw))
+    assert eng.feed_status()["flags"] & 2
+    eng.close()
+    good = (GOLD / "setA.bam").read_bytes()
+    bad = bytearray(good)
+    bad[len(bad) // 2] ^= 0x10
+    refs2, _ = tl.read_bam(GOLD / "setA.bam")
+    eng = pkg.Engine(pss=dict(region_len=15))
+    eng.set_genome_arrays(tl.loaded_contigs(_contigs_of(GOLD / "setA.fa")))
+    eng.set_references([n for n, _ in refs2])
+    eng.submit_bgzf(np.frombuffer(bytes(bad), dtype=np.uint8), header_bytes=_bam_header_bytes(good))
+    assert eng.feed_status()["flags"] & 1
+    eng.close()
