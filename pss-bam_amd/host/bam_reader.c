@@ -106,6 +106,7 @@ struct bam_reader {
     int stop;          /* guarded by mu */
     int header_state;  /* 0 pending, 1 parsed, -1 failed; guarded by mu */
     int hdr_parsed;    /* parse_header() got through */
+    size_t hdr_bytes;  /* inflated bytes in front of the first alignment record */
     pthread_mutex_t mu;
     pthread_cond_t cv;
     bam_header hdr;
@@ -507,6 +508,7 @@ static void *indexer_main(void *arg)
                 size_t hdr_end = 0;
                 rc = parse_header(r, s->buf + s->start, s->len - s->start, !s->full, &hdr_end);
                 s->start += hdr_end;
+                r->hdr_bytes = hdr_end;
             }
         }
         if (rc == 0) rc = index_slot(r, s);
@@ -728,6 +730,7 @@ void bam_reader_release(bam_reader *r, int slot_id)
 }
 
 int bam_reader_slots(const bam_reader *r) { return r->n_slots; }
+size_t bam_reader_header_bytes(const bam_reader *r) { return r->hdr_bytes; }
 
 void bam_reader_close(bam_reader *r)
 {

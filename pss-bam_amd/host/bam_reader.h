@@ -33,6 +33,7 @@ bam_reader *bam_reader_open(const char *path, int n_threads, size_t batch_bytes,
  * copy has completed; the reader keeps two slots for its own fill/index stages. */
 bam_reader *bam_reader_open_slots(const char *path, int n_threads, size_t batch_bytes, int n_slots, char *err, size_t errlen);
 int bam_reader_slots(const bam_reader *r);
+size_t bam_reader_header_bytes(const bam_reader *r); /* inflated bytes in front of the first alignment record */
 const bam_header *bam_reader_header(const bam_reader *r);
 
 /* Next batch of whole alignment records.  *records points into the reader's own buffer

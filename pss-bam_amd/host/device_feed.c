@@ -1,0 +1,284 @@
+/*
+ * pss-bam_amd/host/device_feed.c -- the BAM feed with the inflate on the GPU.
+ *
+ * Replaces the same thing as bam_reader.c -- the `samtools view` child of the reference
+ * (pss-bam.c:148-162, fragkon.c:84-93) -- but moves the decompression to where the records are
+ * consumed: the host only walks BGZF block headers and hands COMPRESSED chunks to
+ * pssbam_engine_submit_bgzf(); inflate, CRC-32, record index and tally all run on the device
+ * (csrc/inflate_kernels.h).  PCIe carries the file (a tenth to a third of the record bytes) and the
+ * host's cores are out of the data path:
+ *
+ *   loader threads   pread() fixed windows of the file into page-locked staging slots, in parallel
+ *   this thread      walks the block headers of each window in file order (18 + 8 bytes per block),
+ *                    cuts batches that inflate to < 1 GiB, and submits them -- asynchronously, in
+ *                    runs of consecutive batches per GPU (contiguous record blocks)
+ *
+ * Works for files whose BGZF blocks start on record boundaries (everything htslib writes).  When
+ * the device index finds a record crossing blocks (PSSBAM_FEED_RAGGED) the caller re-runs the file
+ * through the host reader, whose indexer follows the chain across blocks.
+ */
+#include "device_feed.h"
+
+#include <errno.h>
+#include <fcntl.h>
+#include <pthread.h>
+#include <stdatomic.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#define MAX_STAGE 40
+#define BLOCKS_PER_SCAN 65536u
+#define OVER ((size_t)128 << 10) /* bytes read past a window: the block that starts inside it ends inside this */
+
+typedef struct {
+    uint8_t *buf;          /* window bytes [k*W, k*W + W + OVER) of the file */
+    size_t len;
+    long free_for;         /* chunk index that may load into this slot next */
+    long loaded;           /* chunk index whose bytes are in buf, or -1 */
+    int io_error;
+} stage_t;
+
+typedef struct {
+    int fd;
+    size_t file_size, W;
+    long n_chunks;
+    stage_t st[MAX_STAGE];
+    int n_st;
+    atomic_long next_chunk;
+    pthread_mutex_t mu;
+    pthread_cond_t cv;
+    int stop;
+} loader_t;
+
+static void *loader_main(void *arg)
+{
+    loader_t *L = (loader_t *)arg;
+    for (;;) {
+        const long k = atomic_fetch_add(&L->next_chunk, 1);
+        if (k >= L->n_chunks) break;
+        stage_t *s = &L->st[k % L->n_st];
+        pthread_mutex_lock(&L->mu);
+        while (s->free_for != k && !L->stop) pthread_cond_wait(&L->cv, &L->mu);
+        const int stop = L->stop;
+        pthread_mutex_unlock(&L->mu);
+        if (stop) break;
+        const size_t off = (size_t)k * L->W;
+        size_t want = L->file_size - off < L->W + OVER ? L->file_size - off : L->W + OVER, got = 0;
+        int bad = 0;
+        while (got < want) {
+            const ssize_t n = pread(L->fd, s->buf + got, want - got, (off_t)(off + got));
+            if (n < 0 && errno == EINTR) continue;
+            if (n <= 0) { bad = 1; break; }
+            got += (size_t)n;
+        }
+        memset(s->buf + got, 0, 16); /* the device decoder may read one dword past the payload */
+        pthread_mutex_lock(&L->mu);
+        s->len = got;
+        s->io_error = bad;
+        s->loaded = k;
+        pthread_cond_broadcast(&L->cv);
+        pthread_mutex_unlock(&L->mu);
+    }
+    return NULL;
+}
+
+static size_t env_size(const char *name, size_t dflt)
+{
+    const char *v = getenv(name);
+    if (!v || !*v) return dflt;
+    const unsigned long long x = strtoull(v, NULL, 10);
+    return x ? (size_t)x : dflt;
+}
+
+int device_feed_enabled(void)
+{
+    const char *v = getenv("PSSBAM_DEVICE_INFLATE");
+    return v ? atoi(v) != 0 : 1;
+}
+
+int run_device_feed(pssbam_engine *const *eng, int n_gpus, const char *path, size_t header_bytes, int run, int verbose,
+                    device_feed_stats *fs)
+{
+    loader_t L;
+    pthread_t th[16];
+    int n_th = 0, rc = -1, registered = 0;
+    uint8_t *stage_base = NULL;
+    pssbam_bgzf_block *blocks = NULL, *grp = NULL;
+    memset(&L, 0, sizeof L);
+    memset(fs, 0, sizeof *fs);
+    struct stat sb;
+    L.fd = open(path, O_RDONLY);
+    if (L.fd < 0 || fstat(L.fd, &sb) != 0 || !S_ISREG(sb.st_mode) || sb.st_size <= 0) {
+        if (L.fd >= 0) close(L.fd);
+        fs->fallback = 1; /* pipes and the like: the host reader copes */
+        return 0;
+    }
+    L.file_size = (size_t)sb.st_size;
+    L.W = env_size("PSSBAM_CHUNK_BYTES", (size_t)32 << 20);
+    if (L.W < ((size_t)1 << 20)) L.W = (size_t)1 << 20;
+    L.W &= ~(size_t)4095;
+    L.n_chunks = (long)((L.file_size + L.W - 1) / L.W);
+    const size_t out_cap = env_size("PSSBAM_FEED_BATCH_BYTES", (size_t)1 << 30); /* inflated bytes per submit */
+    const int max_inflight = n_gpus * run < 2 ? 2 : n_gpus * run;
+    L.n_st = max_inflight + 4 > MAX_STAGE ? MAX_STAGE : max_inflight + 4;
+    if ((long)L.n_st > L.n_chunks + 1) L.n_st = (int)L.n_chunks + 1;
+    const size_t slot_bytes = (L.W + OVER + 4096 + 4095) & ~(size_t)4095;
+    pthread_mutex_init(&L.mu, NULL);
+    pthread_cond_init(&L.cv, NULL);
+    if (posix_memalign((void **)&stage_base, 4096, slot_bytes * (size_t)L.n_st) != 0) { stage_base = NULL; goto done; }
+    blocks = (pssbam_bgzf_block *)malloc(sizeof *blocks * BLOCKS_PER_SCAN);
+    grp = (pssbam_bgzf_block *)malloc(sizeof *grp * BLOCKS_PER_SCAN);
+    if (!blocks || !grp) goto done;
+    for (int i = 0; i < L.n_st; i++) {
+        L.st[i].buf = stage_base + (size_t)i * slot_bytes;
+        L.st[i].free_for = i;
+        L.st[i].loaded = -1;
+    }
+    if (!getenv("PSSBAM_NO_PIN")) registered = pssbam_host_register(stage_base, slot_bytes * (size_t)L.n_st) == 0;
+    {
+        long cpus = sysconf(_SC_NPROCESSORS_ONLN);
+        int want = (int)env_size("PSSBAM_LOADER_THREADS", 6);
+        if (want > 16) want = 16;
+        if (cpus > 0 && want > cpus) want = (int)cpus;
+        if ((long)want > L.n_chunks) want = (int)L.n_chunks;
+        for (int t = 0; t < want; t++)
+            if (pthread_create(&th[n_th], NULL, loader_main, &L) == 0) n_th++;
+        if (!n_th) goto done;
+    }
+
+    /* in-flight submits: (stage slot or -1, engine, ticket); a stage slot is handed back to the loaders
+     * when the last submit that reads it has been copied */
+    struct { long chunk; int g; uint64_t ticket; } fifo[128];
+    int fifo_head = 0, fifo_len = 0;
+    long pending_of_chunk[MAX_STAGE];
+    memset(pending_of_chunk, 0, sizeof pending_of_chunk);
+#define RETIRE()                                                                                         \
+    do {                                                                                                 \
+        const int q = fifo_head;                                                                         \
+        if (pssbam_engine_wait_bgzf_copied(eng[fifo[q].g], fifo[q].ticket)) goto done;                    \
+        stage_t *rs = &L.st[fifo[q].chunk % L.n_st];                                                      \
+        if (--pending_of_chunk[fifo[q].chunk % L.n_st] == 0) {                                            \
+            pthread_mutex_lock(&L.mu);                                                                    \
+            rs->free_for = fifo[q].chunk + L.n_st;                                                        \
+            rs->loaded = -1;                                                                              \
+            pthread_cond_broadcast(&L.cv);                                                                \
+            pthread_mutex_unlock(&L.mu);                                                                  \
+        }                                                                                                 \
+        fifo_head = (fifo_head + 1) % 128;                                                                \
+        fifo_len--;                                                                                       \
+    } while (0)
+
+    size_t pos = 0;                /* file offset of the next BGZF block */
+    size_t skip = header_bytes;    /* inflated bytes still to skip in front of the first record */
+    uint64_t n_submits = 0;
+    for (long k = 0; k < L.n_chunks; k++) {
+        stage_t *s = &L.st[k % L.n_st];
+        pthread_mutex_lock(&L.mu);
+        while (s->loaded != k) pthread_cond_wait(&L.cv, &L.mu);
+        pthread_mutex_unlock(&L.mu);
+        if (s->io_error) { fprintf(stderr, "Error: %s: read failed\n", path); goto done; }
+        const size_t win0 = (size_t)k * L.W, win_end = win0 + L.W; /* blocks STARTING in [win0, win_end) are this chunk's */
+        int submitted_from_chunk = 0;
+        while (pos < win_end && pos < L.file_size) {
+            if (pos < win0) { fprintf(stderr, "Error: %s: BGZF block chain lost\n", path); goto done; }
+            uint64_t consumed = 0, inflated = 0;
+            const int64_t n = pssbam_bgzf_scan(s->buf + (pos - win0), s->len - (pos - win0), blocks, BLOCKS_PER_SCAN, &consumed, &inflated);
+            if (n < 0) { fprintf(stderr, "Error: %s: %s\n", path, pssbam_last_error()); goto done; }
+            if (n == 0) {
+                if (win0 + s->len >= L.file_size) { fprintf(stderr, "Error: %s: truncated BGZF block at end of file\n", path); goto done; }
+                fprintf(stderr, "Error: %s: BGZF block larger than the read-ahead\n", path);
+                goto done;
+            }
+            /* keep the blocks that start inside this window; in_off is relative to buf + (pos - win0) */
+            int64_t keep = 0;
+            size_t start = pos;
+            while (keep < n && start < win_end) {
+                start = pos + (size_t)(blocks[keep].in_off + blocks[keep].in_len + 8);
+                keep++;
+            }
+            const size_t chunk_rel = pos - win0;
+            pos = start;
+            /* cut into submits that inflate to <= out_cap; all-header blocks of the file's start are skipped */
+            int64_t i = 0;
+            while (i < keep && skip > 0 && skip >= blocks[i].isize) { skip -= blocks[i].isize; i++; }
+            while (i < keep) {
+                int64_t j = i;
+                const uint64_t base_out = blocks[i].out_off;
+                while (j < keep && blocks[j].out_off + blocks[j].isize - base_out <= out_cap) j++;
+                if (j == i) j = i + 1;
+                const uint64_t base_in = blocks[i].in_off & ~(uint64_t)3;
+                for (int64_t b = i; b < j; b++) {
+                    grp[b - i] = blocks[b];
+                    grp[b - i].in_off -= base_in;
+                    grp[b - i].out_off -= base_out;
+                }
+                const uint64_t end_in = blocks[j - 1].in_off + blocks[j - 1].in_len;
+                const int g = (int)((n_submits / (uint64_t)run) % (uint64_t)n_gpus);
+                uint64_t ticket = 0;
+                if (pssbam_engine_submit_bgzf(eng[g], s->buf + chunk_rel + base_in, end_in - base_in, grp, (uint32_t)(j - i), (uint32_t)skip,
+                                              &ticket)) {
+                    fprintf(stderr, "Error: GPU engine: %s\n", pssbam_last_error());
+                    goto done;
+                }
+                skip = 0;
+                n_submits++;
+                fs->compressed_bytes += end_in - base_in;
+                const int q = (fifo_head + fifo_len) % 128;
+                fifo[q].chunk = k; fifo[q].g = g; fifo[q].ticket = ticket;
+                fifo_len++;
+                pending_of_chunk[k % L.n_st]++;
+                submitted_from_chunk++;
+                while (fifo_len > max_inflight || fifo_len >= 127) RETIRE();
+                i = j;
+            }
+        }
+        if (!submitted_from_chunk) { /* nothing read this slot: give it straight back */
+            pthread_mutex_lock(&L.mu);
+            s->free_for = k + L.n_st;
+            s->loaded = -1;
+            pthread_cond_broadcast(&L.cv);
+            pthread_mutex_unlock(&L.mu);
+        }
+    }
+    while (fifo_len > 0) RETIRE();
+#undef RETIRE
+    if (pos != L.file_size) { fprintf(stderr, "Error: %s: truncated BGZF block at end of file\n", path); goto done; }
+    fs->n_submits = n_submits;
+    /* how the blocks fared: one word per engine */
+    for (int g = 0; g < n_gpus; g++) {
+        uint32_t f = 0;
+        double ms = 0;
+        uint64_t ib = 0;
+        if (pssbam_engine_feed_status(eng[g], &f, &ms, &ib)) { fprintf(stderr, "Error: GPU engine %d: %s\n", g, pssbam_last_error()); goto done; }
+        fs->flags |= f;
+        fs->inflate_ms += ms;
+        fs->inflated_bytes += ib;
+    }
+    if (fs->flags & (PSSBAM_FEED_RAGGED | PSSBAM_FEED_BAD_RECORD)) fs->fallback = 1; /* the host reader follows records across blocks (and words the diagnosis) */
+    else if (fs->flags & PSSBAM_FEED_BAD_BLOCK) { fprintf(stderr, "Error: %s: BGZF inflate / CRC check failed\n", path); goto done; }
+    if (verbose)
+        fprintf(stderr, "[pssbam] device feed: %llu submits, %.2f GB compressed over PCIe, %.2f GB inflated on the device in %.3f s "
+                        "of kernel time (%.1f GB/s), %d loader threads, %d staging slots of %zu MiB%s\n",
+                (unsigned long long)n_submits, fs->compressed_bytes * 1e-9, fs->inflated_bytes * 1e-9, fs->inflate_ms * 1e-3,
+                fs->inflate_ms > 0 ? fs->inflated_bytes * 1e-6 / fs->inflate_ms : 0.0, n_th, L.n_st, L.W >> 20,
+                fs->fallback ? "; records cross BGZF blocks -> host reader" : "");
+    rc = 0;
+done:
+    pthread_mutex_lock(&L.mu);
+    L.stop = 1;
+    pthread_cond_broadcast(&L.cv);
+    pthread_mutex_unlock(&L.mu);
+    for (int t = 0; t < n_th; t++) pthread_join(th[t], NULL);
+    if (rc) for (int g = 0; g < n_gpus; g++) (void)pssbam_engine_sync(eng[g]); /* nothing may still read the staging slots */
+    if (registered) pssbam_host_unregister(stage_base);
+    free(stage_base);
+    free(blocks);
+    free(grp);
+    if (L.fd >= 0) close(L.fd);
+    pthread_mutex_destroy(&L.mu);
+    pthread_cond_destroy(&L.cv);
+    return rc;
+}

@@ -1,0 +1,28 @@
+/* pss-bam_amd/host/device_feed.h -- BAM feed with the BGZF inflate on the GPU (device_feed.c). */
+#ifndef PSSBAM_DEVICE_FEED_H
+#define PSSBAM_DEVICE_FEED_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "pssbam_hip.h"
+
+typedef struct device_feed_stats {
+    uint64_t n_submits, compressed_bytes, inflated_bytes;
+    double inflate_ms;   /* summed inflate + CRC + index kernel time over the engines */
+    uint32_t flags;      /* PSSBAM_FEED_* seen */
+    int fallback;        /* 1: the file must go through the host reader instead (records cross BGZF
+                            blocks, or the input is not a regular file); the engines then hold
+                            partial counts and must be reset */
+} device_feed_stats;
+
+/* $PSSBAM_DEVICE_INFLATE (default 1) */
+int device_feed_enabled(void);
+
+/* Streams the BGZF file at `path` through eng[0..n_gpus) (genome and references already set):
+ * compressed chunks over PCIe, inflate + CRC + record index + tally on the devices, runs of `run`
+ * consecutive batches per engine.  header_bytes = inflated bytes in front of the first alignment
+ * record.  0 = done (see fs->fallback), -1 = failed after printing a diagnostic. */
+int run_device_feed(pssbam_engine *const *eng, int n_gpus, const char *path, size_t header_bytes, int run, int verbose,
+                    device_feed_stats *fs);
+#endif

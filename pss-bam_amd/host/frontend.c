@@ -17,6 +17,7 @@
 #include <unistd.h>
 
 #include "bam_reader.h"
+#include "device_feed.h"
 #include "sam_reader.h"
 
 int frontend_fast_exit = 0;
@@ -26,7 +27,7 @@ int frontend_fast_exit = 0;
  * reader's slots */
 static bam_reader *early_rd = NULL;
 static char early_path[4096];
-static int early_registered = 0;
+static int early_registered = 0, early_light = 0;
 static pthread_t warmup_thread;
 static int warmup_running = 0;
 
@@ -35,7 +36,7 @@ static void *warmup_main(void *arg)
     (void)arg;
     const int n = env_gpu_count(); /* the first HIP call: runtime start-up happens here */
     for (int g = 0; g < n; g++) (void)pssbam_warmup(g); /* failures surface in pssbam_engine_create */
-    if (early_rd && !getenv("PSSBAM_NO_PIN")) {
+    if (early_rd && !early_light && !getenv("PSSBAM_NO_PIN")) {
         void *base;
         size_t bytes;
         bam_reader_buffer(early_rd, &base, &bytes);
@@ -64,7 +65,11 @@ void frontend_warmup_start(const char *aln_path)
 {
     if (aln_path && strlen(aln_path) < sizeof early_path && file_is_bam(aln_path) == 1) {
         char err[256];
-        early_rd = bam_reader_open_slots(aln_path, 0, 0, feed_slots(env_gpu_count()), err, sizeof err); /* a failure is reported by run_tally's own open */
+        /* device feed: the reader is only asked for the BAM header (two threads, small batches) */
+        early_light = device_feed_enabled();
+        early_rd = early_light ? bam_reader_open_slots(aln_path, 2, (size_t)8 << 20, 3, err, sizeof err)
+                               : bam_reader_open_slots(aln_path, 0, 0, feed_slots(env_gpu_count()), err, sizeof err);
+        /* (a failure is reported by run_tally's own open) */
         if (early_rd) strcpy(early_path, aln_path);
     }
     warmup_running = pthread_create(&warmup_thread, NULL, warmup_main, NULL) == 0;
@@ -133,15 +138,34 @@ int run_tally(const pssbam_config *cfg, Genome *genome, const char *aln_path, in
         pthread_join(warmup_thread, NULL);
         warmup_running = 0;
     }
+    /* BAM: inflate on the GPU (device_feed.c) unless switched off or the cross-check kernel is forced;
+     * the host reader then only parses the header -- and takes over if the file's records cross BGZF
+     * blocks */
+    int device_feed = is_bam && device_feed_enabled() && cfg->kernel != PSSBAM_KERNEL_SIMPLE;
+    int light = 0;
     if (is_bam && early_rd && strcmp(early_path, aln_path) == 0) {
         rd = early_rd;
         early_rd = NULL;
+        light = early_light;
         if (early_registered) {
             bam_reader_buffer(rd, &buf_base, &buf_bytes);
             registered = 1;
         }
+    } else if (is_bam && device_feed) {
+        rd = bam_reader_open_slots(aln_path, 2, (size_t)8 << 20, 3, err, sizeof err);
+        light = 1;
     } else if (is_bam) rd = bam_reader_open_slots(aln_path, 0, 0, feed_slots(n_gpus), err, sizeof err);
     else sd = sam_reader_open(aln_path, 0, err, sizeof err);
+    if (is_bam && !rd && light) { /* e.g. a header larger than the light reader's batches: the full reader decides */
+        light = 0;
+        device_feed = 0;
+        rd = bam_reader_open_slots(aln_path, 0, 0, feed_slots(n_gpus), err, sizeof err);
+    }
+    if (rd && light && !device_feed) { /* opened early for the device feed, which is not wanted after all */
+        bam_reader_close(rd);
+        light = 0;
+        rd = bam_reader_open_slots(aln_path, 0, 0, feed_slots(n_gpus), err, sizeof err);
+    }
     if (!rd && !sd) {
         fprintf(stderr, "Error: Unable to open %s: %s\n", aln_path, err);
         return -1;
@@ -157,7 +181,30 @@ int run_tally(const pssbam_config *cfg, Genome *genome, const char *aln_path, in
         }
     }
     t_engine = now_s() - t_mark; t_mark = now_s();
-    if (rd && !registered && !getenv("PSSBAM_NO_PIN")) {
+    device_feed_stats dfs;
+    memset(&dfs, 0, sizeof dfs);
+    int fed_on_device = 0;
+    if (device_feed && rd) {
+        const bam_header *h = bam_reader_header(rd);
+        for (int g = 0; g < n_gpus; g++)
+            if (pssbam_engine_set_references(eng[g], h->n_ref, (const char *const *)h->ref_name)) {
+                fprintf(stderr, "Error: GPU engine %d: %s\n", g, pssbam_last_error());
+                goto done;
+            }
+        refs_sent = h->n_ref;
+        if (run_device_feed(eng, n_gpus, aln_path, bam_reader_header_bytes(rd), feed_run(n_gpus), verbose, &dfs)) goto done;
+        if (dfs.fallback) {
+            if (verbose) fprintf(stderr, "[pssbam] device feed not usable for this file: falling back to the host reader\n");
+            for (int g = 0; g < n_gpus; g++)
+                if (pssbam_engine_reset(eng[g])) { fprintf(stderr, "Error: GPU engine %d: %s\n", g, pssbam_last_error()); goto done; }
+            bam_reader_close(rd);
+            rd = bam_reader_open_slots(aln_path, 0, 0, feed_slots(n_gpus), err, sizeof err);
+            light = 0;
+            if (!rd) { fprintf(stderr, "Error: Unable to open %s: %s\n", aln_path, err); goto done; }
+        } else fed_on_device = 1;
+        t_submit = now_s() - t_mark; t_mark = now_s();
+    }
+    if (rd && !fed_on_device && !registered && !getenv("PSSBAM_NO_PIN")) {
         bam_reader_buffer(rd, &buf_base, &buf_bytes);
         registered = pssbam_host_register(buf_base, buf_bytes) == 0; /* best effort: pageable works too */
     }
@@ -201,7 +248,7 @@ int run_tally(const pssbam_config *cfg, Genome *genome, const char *aln_path, in
         fifo_len--;                                                                                            \
     } while (0)
 
-    for (int turn = 0;; turn++) {
+    for (int turn = 0; !fed_on_device; turn++) {
         const uint8_t *recs;
         const uint32_t *offs;
         size_t nbytes;
@@ -295,12 +342,12 @@ int run_tally(const pssbam_config *cfg, Genome *genome, const char *aln_path, in
     if (verbose)
         fprintf(stderr, "[pssbam] phases: open %.3f engine+genome %.3f pin %.3f read(wait) %.3f submit %.3f reduce+finish %.3f s\n",
                 t_open, t_engine, t_register, t_read, t_submit, t_finish);
-    if (verbose && rd) {
+    if (verbose && rd && !fed_on_device) {
         double ph[4];
         bam_reader_phase_seconds(rd, ph);
         fprintf(stderr, "[pssbam] reader thread: scan+carry %.3f inflate %.3f index %.3f wait-for-slot %.3f s\n", ph[0], ph[1], ph[2], ph[3]);
     }
-    res->inflate_s = rd ? bam_reader_inflate_seconds(rd) : 0.0;
+    res->inflate_s = fed_on_device ? dfs.inflate_ms * 1e-3 : rd ? bam_reader_inflate_seconds(rd) : 0.0;
     if (sd) res->stats[PSSBAM_ST_PARSE_SKIP] += sam_reader_lines_skipped(sd), res->stats[PSSBAM_ST_RECORDS] += sam_reader_lines_skipped(sd);
     res->n_gpus = n_gpus;
     rc = 0;

@@ -230,3 +230,62 @@ def test_feed_flags_ragged_layout_and_damage(pkg, tmp_path):
     eng.submit_bgzf(np.frombuffer(bytes(bad), dtype=np.uint8), header_bytes=_bam_header_bytes(good))
     assert eng.feed_status()["flags"] & 1
     eng.close()
+
+
+def test_cli_device_feed_and_fallback(pkg, oracle, tmp_path):
+    """bin/pss-bam / bin/fragkon with the inflate on the device: htslib-layout BAMs are fed compressed
+    (many small chunks and submits, two engines), a BAM whose records cross BGZF blocks falls back to
+    the host reader, PSSBAM_DEVICE_INFLATE=0 keeps the host path -- identical tables every way"""
+    import os
+    import re
+    import subprocess
+    from pss_bam_amd import synth
+    d = synth.config("C4", scale_genome=0.002, n_reads=400_000)
+    region_len = d.pop("region_len")
+    cfg = synth.make_cfg(**d)
+    fa, sam = tmp_path / "g.fa", tmp_path / "a.sam"
+    synth.fasta_host(cfg, fa)
+    synth.sam_host(cfg, 0, 400_000, sam)
+    g = oracle.load_genome(fa)
+    po, ko = tl.PssOpts(region_len=region_len, min_mq=20), tl.FkOpts(klen=5)
+    wf, wr, st = oracle.pss(g, sam, po)
+    w5, w3, _ = oracle.fragkon(g, sam, ko)
+    oracle.free_genome(g)
+    aligned, ragged = tmp_path / "aligned.bam", tmp_path / "ragged.bam"
+    synth.bam_file_host(cfg, 0, 400_000, aligned, level=1, threads=4)
+    synth.bam_file_host(cfg, 0, 400_000, ragged, level=6, threads=4, ragged=True)
+    b = pkg.PKG_DIR / "bin"
+
+    def run_pss(bam, extra):
+        env = {**os.environ, "PSSBAM_STATS": "1", **extra}
+        pr = subprocess.run([str(b / "pss-bam"), "-F", str(fa), "-B", str(bam), "-o", str(tmp_path / "o")] + po.argv(),
+                            capture_output=True, text=True, env=env)
+        assert pr.returncode == 0, pr.stderr[-3000:]
+        gf, gr = tl.parse_counts_text((tmp_path / "o.pss.counts.txt").read_text())
+        assert np.array_equal(gf, wf) and np.array_equal(gr, wr), extra
+        assert f"[pssbam] records=400000" in pr.stderr and f"[pssbam] pss_ok={st[tl.ST_OK]}" in pr.stderr
+        return pr.stderr
+
+    err = run_pss(aligned, {})
+    m = re.search(r"device feed: (\d+) submits", err)
+    assert m and "host reader" not in err, err[-1500:]
+    err = run_pss(aligned, {"PSSBAM_CHUNK_BYTES": str(1 << 20), "PSSBAM_FEED_BATCH_BYTES": str(3 << 20), "PSSBAM_NGPU": "2",
+                            "PSSBAM_OVERSUBSCRIBE": "1", "PSSBAM_LOADER_THREADS": "3"})
+    m = re.search(r"device feed: (\d+) submits", err)
+    assert m and int(m.group(1)) >= 10 and "gpus=2" in err
+    err = run_pss(ragged, {})
+    assert "falling back to the host reader" in err
+    err = run_pss(aligned, {"PSSBAM_DEVICE_INFLATE": "0"})
+    assert "device feed" not in err
+    pr = subprocess.run([str(b / "fragkon"), "-F", str(fa), "-B", str(aligned)] + ko.argv(), capture_output=True, text=True)
+    assert pr.returncode == 0, pr.stderr
+    g5, g3 = tl.parse_fragkon_text(pr.stdout)
+    assert np.array_equal(g5, w5) and np.array_equal(g3, w3)
+    # a damaged block is a diagnosed failure, not a wrong table
+    raw = bytearray(aligned.read_bytes())
+    raw[len(raw) // 2] ^= 0x20
+    bad = tmp_path / "bad.bam"
+    bad.write_bytes(bytes(raw))
+    pr = subprocess.run([str(b / "pss-bam"), "-F", str(fa), "-B", str(bad), "-o", str(tmp_path / "x")] + po.argv(),
+                        capture_output=True, text=True)
+    assert pr.returncode != 0 and "Error" in pr.stderr
