@@ -475,11 +475,16 @@ def e2e_leg(pkg, synth, cd, region_len, n_reads, resident_reads, resident_counte
         t = time.perf_counter()
         synth.bam_file_host(cfg, 0, n_reads, bam, level=1, threads=threads)
         t_bam = time.perf_counter() - t
-        env = {**os.environ, "PSSBAM_STATS": "1"}
-        t = time.perf_counter()
-        pr = subprocess.run([str(pkg.PKG_DIR / "bin" / "pss-bam"), "-F", str(fa), "-B", str(bam), "-o", str(tmp / "out"),
-                             "-r", str(region_len)], capture_output=True, text=True, env=env, timeout=1500)
-        wall = time.perf_counter() - t
+        def run_cli(extra_env, prefix):
+            env = {**os.environ, "PSSBAM_STATS": "1", **extra_env}
+            t = time.perf_counter()
+            pr = subprocess.run([str(pkg.PKG_DIR / "bin" / "pss-bam"), "-F", str(fa), "-B", str(bam), "-o", str(tmp / prefix),
+                                 "-r", str(region_len)], capture_output=True, text=True, env=env, timeout=1500)
+            return pr, time.perf_counter() - t
+
+        # the same command with the inflate kept on the host threads (round 1's feed), for comparison
+        pr_h, wall_h = run_cli({"PSSBAM_DEVICE_INFLATE": "0"}, "out_host")
+        pr, wall = run_cli({}, "out")
         if pr.returncode != 0:
             return {"error": pr.stderr[-1500:]}
         grab = lambda pat: (lambda mm: mm.group(1) if mm else None)(re.search(pat, pr.stderr))
@@ -505,6 +510,11 @@ def e2e_leg(pkg, synth, cd, region_len, n_reads, resident_reads, resident_counte
             "wall_s": wall, "reads_per_s": n_reads / wall,
             "tally_phase_s": tally_s, "reads_per_s_tally_phase": n_reads / tally_s if tally_s else None,
             "fasta_load_s": stages.get("fasta load"), "stages_s": stages,
+            "feed": "device inflate" if "device feed:" in pr.stderr and "falling back" not in pr.stderr else "host inflate",
+            "device_feed": grab(r"device feed: (.*)\n"),
+            "host_inflate_run": ({"wall_s": wall_h, "reads_per_s": n_reads / wall_h,
+                                  "tables_identical": bool(all(np.array_equal(a, b) for a, b in zip(tl.parse_counts_text((tmp / "out_host.pss.counts.txt").read_text()), tl.parse_counts_text((tmp / "out.pss.counts.txt").read_text()))))}
+                                 if pr_h.returncode == 0 else {"error": pr_h.stderr[-500:]}),
             "tables_check": check, "note": note,
             "workload_gen_s": {"fasta": t_fa, "bam": t_bam},
         }

@@ -171,8 +171,15 @@ extern "C" int pssbam_bgzf_inflate_host(int device, const void *bgzf, uint64_t n
 }
 
 // --------------------------------------------------------------------------------------
-// the feed: compressed batch -> device inflate -> device record index -> tally, one call
+// the feed: compressed chunks -> device inflate -> device record index -> tally
 // --------------------------------------------------------------------------------------
+// The inflate kernel runs one lane per BGZF block, so it wants hundreds of thousands of blocks per
+// launch (49 152 lanes are resident; a 1 GiB batch holds 16 000 blocks).  submit_bgzf therefore only
+// COPIES its chunk and appends its blocks to the super-batch being assembled; when that has
+// collected feed_out_target bytes of output (12 GiB: ~200 000 blocks, four rounds of lanes) it is
+// flushed: one inflate launch + one CRC launch over all blocks, then per < 4 GiB sub-batch (the
+// tally kernels index records with u32 offsets) the record index and the tally.  Two super-batches
+// alternate, so chunks keep arriving over PCIe while the previous one is inflated.
 template <class T>
 static int grow(T **ptr, size_t *cap, size_t need, size_t elem = sizeof(T)) {
     if (*cap >= need) return PSSBAM_OK;
@@ -183,6 +190,73 @@ static int grow(T **ptr, size_t *cap, size_t need, size_t elem = sizeof(T)) {
     return PSSBAM_OK;
 }
 
+static constexpr uint64_t FEED_SUB_MAX = (3584ull << 20);   // records per tally launch: below 4 GiB
+
+static int feed_flush(pssbam_engine *e) {
+    FeedAcc &s = e->feed[e->cur_feed];
+    if (s.blocks.empty()) return PSSBAM_OK;
+    int rc;
+    const size_t nb = s.blocks.size();
+    if (nb > 0xFFFFFFF0ull) return fail(PSSBAM_EINVAL, "too many BGZF blocks in one super-batch");
+    size_t bc = s.blocks_cap, bc2 = s.blocks_cap, bc3 = s.blocks_cap;
+    if ((rc = grow((uint8_t **)&s.d_blocks, &bc, nb, sizeof(pssbam::BgzfBlock)))) return rc;
+    if ((rc = grow(&s.d_counts, &bc2, nb))) return rc;
+    if ((rc = grow(&s.d_base, &bc3, nb))) return rc;
+    s.blocks_cap = std::min(bc, std::min(bc2, bc3));
+    if ((rc = grow(&s.d_offs, &s.offs_cap, (size_t)(s.out_used / 36ull + 2ull * s.sub_first.size() + 16ull)))) return rc;
+    if ((rc = grow(&s.d_nrecs, &s.nrecs_cap, s.sub_first.size()))) return rc;
+    // every chunk of this super-batch has been issued on the copy streams: the engine's stream waits for them
+    if (!s.copies_done) HIP_TRY(hipEventCreateWithFlags(&s.copies_done, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(s.copies_done, e->copy_stream));
+    HIP_TRY(hipStreamWaitEvent(e->stream, s.copies_done, 0));
+    HIP_TRY(hipMemcpyAsync(s.d_blocks, s.blocks.data(), nb * sizeof(pssbam_bgzf_block), hipMemcpyHostToDevice, e->stream));
+    hipEvent_t ev0 = take_event(e), ev1 = take_event(e);
+    if (!ev0 || !ev1) return fail(PSSBAM_EHIP, "hipEventCreate failed");
+    HIP_TRY(hipEventRecord(ev0, e->stream));
+    rc = pssbam_bgzf_inflate_device(e->stream, s.d_comp, s.comp_used, (pssbam_bgzf_block *)s.d_blocks, (uint32_t)nb, s.d_out,
+                                    getenv("PSSBAM_NO_CRC") ? 0 : 1);
+    if (rc) return rc;
+    // record index per sub-batch
+    uint64_t offs_at = 0;
+    std::vector<uint64_t> sub_offs(s.sub_first.size()), sub_base(s.sub_first.size()), sub_len(s.sub_first.size());
+    for (size_t k = 0; k < s.sub_first.size(); k++) {
+        const uint32_t b0 = s.sub_first[k], b1 = k + 1 < s.sub_first.size() ? s.sub_first[k + 1] : (uint32_t)nb;
+        const uint64_t base = s.blocks[b0].out_off, len = s.blocks[b1 - 1].out_off + s.blocks[b1 - 1].isize - base;
+        sub_offs[k] = offs_at;
+        sub_base[k] = base;
+        sub_len[k] = len;
+        const uint32_t n = b1 - b0;
+        const uint32_t igrid = std::min<uint32_t>((n + 255u) / 256u, (uint32_t)e->n_cu * 8u);
+        const pssbam::BgzfBlock *blk = (const pssbam::BgzfBlock *)s.d_blocks + b0;
+        hipLaunchKernelGGL(pssbam::bgzf_index_count, dim3(igrid), dim3(256), 0, e->stream, (const uint8_t *)s.d_out, blk, n, s.sub_skip[k],
+                           s.d_counts + b0, e->d_feed_flags);
+        hipLaunchKernelGGL(pssbam::bgzf_index_scan, dim3(1), dim3(1024), 0, e->stream, (const uint32_t *)(s.d_counts + b0), n, s.d_base + b0,
+                           s.d_nrecs + k);
+        hipLaunchKernelGGL(pssbam::bgzf_index_write, dim3(igrid), dim3(256), 0, e->stream, (const uint8_t *)s.d_out, blk, n, s.sub_skip[k],
+                           (const uint32_t *)(s.d_counts + b0), (const uint32_t *)(s.d_base + b0), s.d_offs + offs_at, (const uint32_t *)(s.d_nrecs + k),
+                           base, (uint32_t)len);
+        offs_at += len / 36ull + 2ull;
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ev1, e->stream));
+    e->inflate_events.emplace_back(ev0, ev1);
+    e->inflated_bytes += s.out_used;
+    for (size_t k = 0; k < s.sub_first.size(); k++) {
+        rc = launch_tally(e, s.d_out + sub_base[k], sub_len[k], s.d_offs + sub_offs[k],
+                          (uint32_t)std::min<uint64_t>(sub_len[k] / 36ull + 2ull, 0xFFFFFFF0ull), nullptr, 0, s.d_nrecs + k, s.sub_skip[k]);
+        if (rc) return rc;
+    }
+    if (!s.consumed) HIP_TRY(hipEventCreateWithFlags(&s.consumed, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(s.consumed, e->stream));
+    s.busy = true;
+    s.blocks.clear();
+    s.sub_first.clear();
+    s.sub_skip.clear();
+    s.comp_used = s.out_used = s.sub_bytes = 0;
+    e->cur_feed ^= 1;
+    return PSSBAM_OK;
+}
+
 extern "C" int pssbam_engine_submit_bgzf(pssbam_engine *e, const void *comp, uint64_t comp_bytes, const pssbam_bgzf_block *blocks,
                                          uint32_t n_blocks, uint32_t first_record_offset, uint64_t *ticket) {
     int rc = check_ready(e);
@@ -190,93 +264,85 @@ extern "C" int pssbam_engine_submit_bgzf(pssbam_engine *e, const void *comp, uin
     if (ticket) *ticket = 0;
     if (!n_blocks) return PSSBAM_OK;
     if (!comp || !blocks) return fail(PSSBAM_EINVAL, "null buffer");
+    if (e->cfg.kernel == PSSBAM_KERNEL_SIMPLE) return fail(PSSBAM_EINVAL, "device-indexed blocks need the tiled kernels");
     const uint64_t out_bytes = blocks[n_blocks - 1].out_off + blocks[n_blocks - 1].isize;
-    if (out_bytes >= (1ull << 32) - (1ull << 16)) return fail(PSSBAM_EINVAL, "batch inflates to %llu bytes; keep batches below 4 GiB", (unsigned long long)out_bytes);
+    if (out_bytes > (2ull << 30)) return fail(PSSBAM_EINVAL, "chunk inflates to %llu bytes; keep chunks below 2 GiB", (unsigned long long)out_bytes);
     if (blocks[0].out_off != 0) return fail(PSSBAM_EINVAL, "blocks[0].out_off must be 0");
     if (first_record_offset > blocks[0].isize) return fail(PSSBAM_EINVAL, "first_record_offset lies beyond the first block");
+    if (comp_bytes > e->feed_comp_cap / 2) return fail(PSSBAM_EINVAL, "chunk of %llu compressed bytes is too large", (unsigned long long)comp_bytes);
     HIP_TRY(hipSetDevice(e->device));
     if (!e->d_feed_flags) {
+        if (getenv("PSSBAM_FEED_SUPER_BYTES")) e->feed_out_target = std::max<uint64_t>(1ull << 20, strtoull(getenv("PSSBAM_FEED_SUPER_BYTES"), nullptr, 10));
         HIP_TRY(hipMalloc(&e->d_feed_flags, sizeof(uint32_t)));
         HIP_TRY(hipMemsetAsync(e->d_feed_flags, 0, sizeof(uint32_t), e->stream));
     }
-    FeedSlot &s = e->feed[e->next_feed];
-    e->next_feed ^= 1;
-    if (!s.copied) {
-        HIP_TRY(hipEventCreate(&s.copy_begin));
-        HIP_TRY(hipEventCreate(&s.copied));
-        HIP_TRY(hipEventCreateWithFlags(&s.consumed, hipEventDisableTiming));
+    // room in the super-batch being assembled?  else launch it and turn to the other one
+    {
+        FeedAcc &cur = e->feed[e->cur_feed];
+        if (!cur.blocks.empty() && (cur.out_used + out_bytes > e->feed_out_target || cur.comp_used + comp_bytes + 32 > e->feed_comp_cap)) {
+            rc = feed_flush(e);
+            if (rc) return rc;
+        }
     }
-    if (s.busy) HIP_TRY(hipEventSynchronize(s.consumed));
-    s.busy = false;
-    if (s.timed) {
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, s.copy_begin, s.copied) == hipSuccess) e->h2d_ms += ms;
-        s.timed = false;
+    FeedAcc &s = e->feed[e->cur_feed];
+    if (s.busy) {   // its previous super-batch must have been consumed before its buffers are overwritten
+        HIP_TRY(hipEventSynchronize(s.consumed));
+        s.busy = false;
     }
-    const uint64_t max_recs = out_bytes / 36ull + 2ull;   // a record is at least 36 bytes
-    size_t bc = s.blocks_cap, bc2 = s.blocks_cap, bc3 = s.blocks_cap;
-    if ((rc = grow(&s.d_comp, &s.comp_cap, (size_t)comp_bytes + 16))) return rc;
-    if ((rc = grow((uint8_t **)&s.d_blocks, &bc, (size_t)n_blocks, sizeof(pssbam::BgzfBlock)))) return rc;
-    if ((rc = grow(&s.d_counts, &bc2, (size_t)n_blocks))) return rc;
-    if ((rc = grow(&s.d_base, &bc3, (size_t)n_blocks))) return rc;
-    s.blocks_cap = std::min(bc, std::min(bc2, bc3));
-    if ((rc = grow(&s.d_out, &s.out_cap, (size_t)out_bytes + 64))) return rc;
-    if ((rc = grow(&s.d_offs, &s.offs_cap, (size_t)max_recs))) return rc;
-    if (!s.d_nrecs) HIP_TRY(hipMalloc(&s.d_nrecs, sizeof(uint32_t)));
-
-    // compressed bytes + block table over PCIe (two copy streams for large batches, like submit)
-    HIP_TRY(hipEventRecord(s.copy_begin, e->copy_stream));
-    const uint64_t half = comp_bytes >= (32ull << 20) ? (comp_bytes / 2) & ~4095ull : 0;
-    if (half) {
-        HIP_TRY(hipStreamWaitEvent(e->copy_stream2, s.copy_begin, 0));
-        HIP_TRY(hipMemcpyAsync(s.d_comp + half, (const uint8_t *)comp + half, comp_bytes - half, hipMemcpyHostToDevice, e->copy_stream2));
-        HIP_TRY(hipEventRecord(e->copied2, e->copy_stream2));
+    if (!s.d_comp) {
+        s.comp_cap = (size_t)e->feed_comp_cap;
+        HIP_TRY(hipMalloc(&s.d_comp, s.comp_cap + 64));
     }
-    HIP_TRY(hipMemcpyAsync(s.d_comp, comp, half ? half : comp_bytes, hipMemcpyHostToDevice, e->copy_stream));
-    HIP_TRY(hipMemcpyAsync(s.d_blocks, blocks, (size_t)n_blocks * sizeof(pssbam_bgzf_block), hipMemcpyHostToDevice, e->copy_stream));
-    if (half) HIP_TRY(hipStreamWaitEvent(e->copy_stream, e->copied2, 0));
-    HIP_TRY(hipEventRecord(s.copied, e->copy_stream));
-    s.timed = true;
-    e->h2d_bytes += comp_bytes + (uint64_t)n_blocks * sizeof(pssbam_bgzf_block);
-    HIP_TRY(hipStreamWaitEvent(e->stream, s.copied, 0));
-
-    // inflate + CRC + record index on the engine's stream
-    hipEvent_t ev0 = take_event(e), ev1 = take_event(e);
-    if (!ev0 || !ev1) return fail(PSSBAM_EHIP, "hipEventCreate failed");
-    HIP_TRY(hipEventRecord(ev0, e->stream));
-    rc = pssbam_bgzf_inflate_device(e->stream, s.d_comp, comp_bytes, (pssbam_bgzf_block *)s.d_blocks, n_blocks, s.d_out,
-                                    getenv("PSSBAM_NO_CRC") ? 0 : 1);
-    if (rc) return rc;
-    const uint32_t igrid = std::min<uint32_t>((n_blocks + 255u) / 256u, (uint32_t)e->n_cu * 8u);
-    hipLaunchKernelGGL(pssbam::bgzf_index_count, dim3(igrid), dim3(256), 0, e->stream, (const uint8_t *)s.d_out,
-                       (const pssbam::BgzfBlock *)s.d_blocks, n_blocks, first_record_offset, s.d_counts, e->d_feed_flags);
-    hipLaunchKernelGGL(pssbam::bgzf_index_scan, dim3(1), dim3(1024), 0, e->stream, (const uint32_t *)s.d_counts, n_blocks, s.d_base, s.d_nrecs);
-    hipLaunchKernelGGL(pssbam::bgzf_index_write, dim3(igrid), dim3(256), 0, e->stream, (const uint8_t *)s.d_out,
-                       (const pssbam::BgzfBlock *)s.d_blocks, n_blocks, first_record_offset, (const uint32_t *)s.d_counts,
-                       (const uint32_t *)s.d_base, s.d_offs, (const uint32_t *)s.d_nrecs, (uint32_t)out_bytes);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(ev1, e->stream));
-    e->inflate_events.emplace_back(ev0, ev1);
-    e->inflated_bytes += out_bytes;
-
-    rc = launch_tally(e, s.d_out, out_bytes, s.d_offs, (uint32_t)std::min<uint64_t>(max_recs, 0xFFFFFFF0ull), nullptr, 0, s.d_nrecs,
-                      first_record_offset);
-    if (rc) return rc;
-    HIP_TRY(hipEventRecord(s.consumed, e->stream));
-    s.busy = true;
-    s.ticket = ++e->ticket_seq;
-    if (ticket) *ticket = s.ticket;
+    const uint64_t need_out = std::max<uint64_t>(e->feed_out_target, s.out_used + out_bytes) + (2ull << 30) + 4096;
+    if (s.out_cap < s.out_used + out_bytes + 4096) {
+        if (s.out_used) return fail(PSSBAM_ESTATE, "output buffer of the super-batch cannot grow while it holds blocks");
+        if ((rc = grow(&s.d_out, &s.out_cap, (size_t)need_out))) return rc;
+    }
+    // blocks: in_off -> into d_comp, out_off -> into d_out; a new tally sub-batch where the record
+    // bytes would pass 3.5 GiB or where bytes must be skipped in front of the first record
+    const uint64_t comp_at = (s.comp_used + 15ull) & ~15ull;
+    for (uint32_t i = 0; i < n_blocks; i++) {
+        pssbam_bgzf_block b = blocks[i];
+        const bool new_sub = s.sub_first.empty() || (i == 0 && first_record_offset) || s.sub_bytes + b.isize > FEED_SUB_MAX;
+        if (new_sub) {
+            s.out_used = (s.out_used + 255ull) & ~255ull;   // a tally launch wants its records 16-byte aligned
+            s.sub_first.push_back((uint32_t)s.blocks.size());
+            s.sub_skip.push_back(i == 0 ? first_record_offset : 0u);
+            s.sub_bytes = 0;
+        }
+        b.in_off += comp_at;
+        b.out_off = s.out_used;
+        b.status = 0;
+        s.out_used += b.isize;
+        s.sub_bytes += b.isize;
+        s.blocks.push_back(b);
+    }
+    // the chunk's bytes over PCIe, alternating between the two copy streams
+    hipStream_t cs = (e->ticket_seq & 1u) ? e->copy_stream2 : e->copy_stream;
+    HIP_TRY(hipMemcpyAsync(s.d_comp + comp_at, comp, comp_bytes, hipMemcpyHostToDevice, cs));
+    hipEvent_t done = nullptr;
+    if (!e->feed_event_pool.empty()) { done = e->feed_event_pool.back(); e->feed_event_pool.pop_back(); }
+    else HIP_TRY(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(done, cs));
+    if (cs == e->copy_stream2) HIP_TRY(hipStreamWaitEvent(e->copy_stream, done, 0));   // flush waits on copy_stream alone
+    s.comp_used = comp_at + comp_bytes;
+    e->h2d_bytes += comp_bytes;
+    const uint64_t t = ++e->ticket_seq;
+    e->feed_copies.emplace_back(t, done);
+    if (ticket) *ticket = t;
     return PSSBAM_OK;
 }
 
-// copy completion of a submit_bgzf ticket (the compressed staging buffer is then free)
+// copy completion of a submit_bgzf ticket (the caller's compressed chunk is then free)
 extern "C" int pssbam_engine_wait_bgzf_copied(pssbam_engine *e, uint64_t ticket) {
     if (!e) return fail(PSSBAM_EINVAL, "null engine");
     if (!ticket) return PSSBAM_OK;
-    for (FeedSlot &s : e->feed)
-        if (s.ticket == ticket) {
+    for (size_t i = 0; i < e->feed_copies.size(); i++)
+        if (e->feed_copies[i].first == ticket) {
             HIP_TRY(hipSetDevice(e->device));
-            HIP_TRY(hipEventSynchronize(s.copied));
+            HIP_TRY(hipEventSynchronize(e->feed_copies[i].second));
+            e->feed_event_pool.push_back(e->feed_copies[i].second);
+            e->feed_copies.erase(e->feed_copies.begin() + (long)i);
             return PSSBAM_OK;
         }
     return PSSBAM_OK;

@@ -77,10 +77,15 @@ struct Slot {  // one in-flight host-submitted block
     uint64_t ticket = 0;      // the submit that last used the slot
 };
 
-struct FeedSlot {  // one in-flight compressed batch (pssbam_engine_submit_bgzf)
-    uint8_t *d_comp = nullptr;
+struct FeedAcc {  // one super-batch of compressed blocks: assembled chunk by chunk, then inflated in ONE launch
+    uint8_t *d_comp = nullptr;      // compressed bytes of the chunks, back to back (each 16-byte aligned)
     size_t comp_cap = 0;
-    void *d_blocks = nullptr;       // pssbam::BgzfBlock[]
+    uint64_t comp_used = 0;
+    std::vector<pssbam_bgzf_block> blocks;   // in_off into d_comp, out_off into d_out
+    std::vector<uint32_t> sub_first;         // first block of every tally sub-batch (< 4 GiB of records each)
+    std::vector<uint32_t> sub_skip;          // bytes in front of the first record of that block (BAM header)
+    uint64_t out_used = 0, sub_bytes = 0;
+    void *d_blocks = nullptr;                // pssbam::BgzfBlock[]
     uint32_t *d_counts = nullptr, *d_base = nullptr;
     size_t blocks_cap = 0;
     uint8_t *d_out = nullptr;
@@ -88,9 +93,9 @@ struct FeedSlot {  // one in-flight compressed batch (pssbam_engine_submit_bgzf)
     uint32_t *d_offs = nullptr;
     size_t offs_cap = 0;
     uint32_t *d_nrecs = nullptr;
-    hipEvent_t copy_begin = nullptr, copied = nullptr, consumed = nullptr;
-    bool busy = false, timed = false;
-    uint64_t ticket = 0;
+    size_t nrecs_cap = 0;
+    hipEvent_t consumed = nullptr, copies_done = nullptr;
+    bool busy = false;
 };
 
 struct pssbam_engine {
@@ -131,8 +136,11 @@ struct pssbam_engine {
     double h2d_ms = 0.0;      // summed H2D copy durations (events on the copy stream)
     uint64_t h2d_bytes = 0;
     // device-side inflate feed
-    FeedSlot feed[2];
-    int next_feed = 0;
+    FeedAcc feed[2];
+    int cur_feed = 0;
+    uint64_t feed_out_target = 12ull << 30, feed_comp_cap = 4ull << 30;   // per super-batch
+    std::vector<std::pair<uint64_t, hipEvent_t>> feed_copies;             // (ticket, copy-complete event) of submits
+    std::vector<hipEvent_t> feed_event_pool;
     uint32_t *d_feed_flags = nullptr;
     double inflate_ms = 0.0;  // summed inflate + CRC + index kernel durations
     uint64_t inflated_bytes = 0;
@@ -266,7 +274,7 @@ extern "C" void pssbam_engine_destroy(pssbam_engine *e) {
         if (s.copy_begin) (void)hipEventDestroy(s.copy_begin);
         if (s.consumed) (void)hipEventDestroy(s.consumed);
     }
-    for (FeedSlot &s : e->feed) {
+    for (FeedAcc &s : e->feed) {
         if (s.d_comp) (void)hipFree(s.d_comp);
         if (s.d_blocks) (void)hipFree(s.d_blocks);
         if (s.d_counts) (void)hipFree(s.d_counts);
@@ -274,10 +282,11 @@ extern "C" void pssbam_engine_destroy(pssbam_engine *e) {
         if (s.d_out) (void)hipFree(s.d_out);
         if (s.d_offs) (void)hipFree(s.d_offs);
         if (s.d_nrecs) (void)hipFree(s.d_nrecs);
-        if (s.copy_begin) (void)hipEventDestroy(s.copy_begin);
-        if (s.copied) (void)hipEventDestroy(s.copied);
         if (s.consumed) (void)hipEventDestroy(s.consumed);
+        if (s.copies_done) (void)hipEventDestroy(s.copies_done);
     }
+    for (auto &p : e->feed_copies) (void)hipEventDestroy(p.second);
+    for (hipEvent_t ev : e->feed_event_pool) (void)hipEventDestroy(ev);
     if (e->d_feed_flags) (void)hipFree(e->d_feed_flags);
     for (auto &p : e->inflate_events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (auto &p : e->launch_events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
@@ -789,9 +798,15 @@ extern "C" int pssbam_engine_phase_times(pssbam_engine *e, double *h2d_ms, uint6
     return PSSBAM_OK;
 }
 
+static int feed_flush(pssbam_engine *e);
+
 extern "C" int pssbam_engine_sync(pssbam_engine *e) {
     if (!e) return fail(PSSBAM_EINVAL, "null engine");
     HIP_TRY(hipSetDevice(e->device));
+    {
+        const int rc = feed_flush(e);   // compressed blocks still being collected (pssbam_engine_submit_bgzf)
+        if (rc) return rc;
+    }
     HIP_TRY(hipStreamSynchronize(e->copy_stream2));
     HIP_TRY(hipStreamSynchronize(e->copy_stream));
     HIP_TRY(hipStreamSynchronize(e->stream));

@@ -498,14 +498,15 @@ __global__ void __launch_bounds__(1024) bgzf_index_scan(const uint32_t *counts, 
 
 __global__ void __launch_bounds__(256) bgzf_index_write(const uint8_t *out, const BgzfBlock *blocks, uint32_t n_blocks,
                                                         uint32_t first_off, const uint32_t *counts, const uint32_t *base,
-                                                        uint32_t *offs, const uint32_t *total, uint32_t batch_bytes) {
+                                                        uint32_t *offs, const uint32_t *total, uint64_t batch_base,
+                                                        uint32_t batch_bytes) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_blocks; i += gridDim.x * blockDim.x) {
         const BgzfBlock b = blocks[i];
         const uint8_t *p = out + b.out_off;
         uint32_t o = i == 0u ? first_off : 0u, k = base[i];
         const uint32_t k_end = k + counts[i];
         while (k < k_end) {   // the same walk as bgzf_index_count, bounded by its count
-            offs[k++] = (uint32_t)b.out_off + o;
+            offs[k++] = (uint32_t)(b.out_off - batch_base) + o;   // relative to the tally launch's record base
             o += 4u + load_u32_unaligned(p + o);
         }
         if (i == n_blocks - 1u) offs[*total] = batch_bytes;
