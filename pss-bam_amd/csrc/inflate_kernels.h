@@ -133,6 +133,12 @@ __device__ __forceinline__ uint64_t load_u64(const uint8_t *p) {
     return v;
 }
 __device__ __forceinline__ void store_u64(uint8_t *p, uint64_t v) { __builtin_memcpy(p, &v, 8); }
+__device__ __forceinline__ uint4 load_u128(const uint8_t *p) {
+    uint4 v;
+    __builtin_memcpy(&v, p, 16);
+    return v;
+}
+__device__ __forceinline__ void store_u128(uint8_t *p, uint4 v) { __builtin_memcpy(p, &v, 16); }
 
 // One BGZF block by one lane.  Returns INF_*.
 __device__ uint32_t inflate_block(const uint8_t *comp, uint64_t comp_bytes, const BgzfBlock &b, uint8_t *outbuf, const LaneLds &t) {
@@ -331,7 +337,28 @@ __device__ uint32_t inflate_block(const uint8_t *comp, uint64_t comp_bytes, cons
                 if (len > isize - pos) return INF_OVERRUN;
                 uint8_t *dst = out + pos;
                 pos += len;
-                if (dist >= 8u) {
+                if (dist >= 64u) {
+                    // far matches (the usual case in a BAM: the previous record): 32 bytes per step, and the
+                    // loads of step i+1 are issued BEFORE the stores of step i (they cannot overlap them:
+                    // src + 64 <= dst) -- the wait for a load then does not include the younger stores
+                    // (vmcnt retires in order), so a step costs one load round trip, not a store + a load
+                    const uint8_t *src = dst - dist;
+                    if (len >= 32u) {
+                        uint4 a = load_u128(src), b = load_u128(src + 16);
+                        while (len >= 64u) {
+                            const uint4 na = load_u128(src + 32), nb = load_u128(src + 48);
+                            store_u128(dst, a);
+                            store_u128(dst + 16, b);
+                            a = na; b = nb;
+                            dst += 32; src += 32; len -= 32u;
+                        }
+                        store_u128(dst, a);
+                        store_u128(dst + 16, b);
+                        dst += 32; src += 32; len -= 32u;
+                    }
+                    while (len >= 8u) { store_u64(dst, load_u64(src)); dst += 8; src += 8; len -= 8u; }
+                    for (uint32_t i = 0; i < len; i++) dst[i] = src[i];
+                } else if (dist >= 8u) {
                     const uint8_t *src = dst - dist;
                     while (len >= 8u) { store_u64(dst, load_u64(src)); dst += 8; src += 8; len -= 8u; }
                     for (uint32_t i = 0; i < len; i++) dst[i] = src[i];
@@ -418,11 +445,18 @@ __global__ void __launch_bounds__(256) bgzf_crc_kernel(const uint8_t *out, BgzfB
         const uint32_t s = e > CRC_CHUNK ? e - CRC_CHUNK : 0u;
         uint32_t crc = (s == 0u && e > 0u) ? 0xFFFFFFFFu : 0u;
         const uint8_t *p = out + b.out_off;
+        // 16 bytes per load: the lanes of a wave read 1 KiB apart (one cache line each), so a dword at a
+        // time would fetch every line 32 times over
         uint32_t i = s;
-        for (; i < e && ((uintptr_t)(p + i) & 3u); i++) crc = tab[0][(crc ^ p[i]) & 0xFFu] ^ (crc >> 8);
-        for (; i + 4u <= e; i += 4u) {
-            const uint32_t w = *(const uint32_t *)(p + i) ^ crc;
-            crc = tab[3][w & 0xFFu] ^ tab[2][(w >> 8) & 0xFFu] ^ tab[1][(w >> 16) & 0xFFu] ^ tab[0][w >> 24];
+        for (; i < e && ((uintptr_t)(p + i) & 15u); i++) crc = tab[0][(crc ^ p[i]) & 0xFFu] ^ (crc >> 8);
+        for (; i + 16u <= e; i += 16u) {
+            const uint4 q = *(const uint4 *)(p + i);
+            const uint32_t d[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t w = d[k] ^ crc;
+                crc = tab[3][w & 0xFFu] ^ tab[2][(w >> 8) & 0xFFu] ^ tab[1][(w >> 16) & 0xFFu] ^ tab[0][w >> 24];
+            }
         }
         for (; i < e; i++) crc = tab[0][(crc ^ p[i]) & 0xFFu] ^ (crc >> 8);
         if (behind && e > 0u) crc = gf2_mul(crc, xpow_kib[63u - lane]);

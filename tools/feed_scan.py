@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
-"""tools/feed_scan.py -- GPU-box helper: one generated BAM + FASTA, bin/pss-bam run under several
-environment settings (inflate thread counts, copy streams); prints the front end's phase lines."""
+"""tools/feed_scan.py -- GPU-box helper: bin/pss-bam on ONE generated BAM + FASTA of the benchmark shape under
+several feed settings (environment variables), wall seconds each.
+    python3 tools/feed_scan.py [--reads 200000000] [--scale-genome 1.0] -- "VAR=val VAR2=val" "VAR=val" ..."""
+import argparse
+import json
 import os
+import re
 import subprocess
 import sys
 import tempfile
@@ -10,30 +14,57 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
 import __graft_entry__ as ge  # noqa: E402
+import bench  # noqa: E402
 
+argv = sys.argv[1:]
+settings = [""]
+if "--" in argv:
+    k = argv.index("--")
+    settings = argv[k + 1:]
+    argv = argv[:k]
+ap = argparse.ArgumentParser()
+ap.add_argument("--reads", type=int, default=200_000_000)
+ap.add_argument("--scale-genome", type=float, default=1.0)
+ap.add_argument("--config", default="C3")
+ap.add_argument("--level", type=int, default=1)
+args = ap.parse_args(argv)
 pkg = ge.load_pkg()
 from pss_bam_amd import synth  # noqa: E402
 
-reads = int(sys.argv[1]) if len(sys.argv) > 1 else 60_000_000
-d = synth.config("C2", n_reads=reads, scale_genome=0.1)
+threads = bench.worker_threads()
+d = synth.config(args.config, scale_genome=args.scale_genome)
 region_len = d.pop("region_len")
 d.pop("klen", None)
 cfg = synth.make_cfg(**d)
 tmp = Path(tempfile.mkdtemp(prefix="pssbam_scan_", dir=os.environ.get("TMPDIR", "/tmp")))
 fa, bam = tmp / "ref.fa", tmp / "reads.bam"
-threads = os.cpu_count() or 8
 synth.fasta_host(cfg, fa, threads=threads)
-synth.bam_file_host(cfg, 0, reads, bam, level=1, threads=threads)
-settings = [{"PSSBAM_INFLATE_THREADS": t} for t in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["32", "48", "64"])]
-for env in settings:
+synth.bam_file_host(cfg, 0, args.reads, bam, level=args.level, threads=threads)
+print(f"[feed_scan] {args.reads} reads, BAM {bam.stat().st_size / 1e9:.2f} GB, FASTA {fa.stat().st_size / 1e9:.2f} GB", flush=True)
+ref_counts = None
+for st in settings:
+    env = {**os.environ, "PSSBAM_STATS": "1"}
+    for kv in st.split():
+        k, v = kv.split("=", 1)
+        env[k] = v
+    best = None
     for rep in range(2):
-        t = time.time()
-        pr = subprocess.run([str(pkg.PKG_DIR / "bin" / "pss-bam"), "-F", str(fa), "-B", str(bam), "-o", str(tmp / "out"), "-r", str(region_len)],
-                            capture_output=True, text=True, env={**os.environ, "PSSBAM_STATS": "1", **env})
-        wall = time.time() - t
-        lines = [ln for ln in pr.stderr.splitlines() if "phases" in ln or "reader thread" in ln]
-        print(env, f"wall {wall:.3f}", " | ".join(ln.replace("[pssbam] ", "") for ln in lines), flush=True)
+        t = time.perf_counter()
+        pr = subprocess.run([str(pkg.PKG_DIR / "bin" / "pss-bam"), "-F", str(fa), "-B", str(bam), "-o", str(tmp / "o"), "-r", str(region_len)],
+                            capture_output=True, text=True, env=env)
+        wall = time.perf_counter() - t
+        assert pr.returncode == 0, pr.stderr[-2000:]
+        if best is None or wall < best[0]:
+            best = (wall, pr.stderr)
+    counts = "\n".join((tmp / "o.pss.counts.txt").read_text().splitlines()[6:])
+    ref_counts = ref_counts or counts
+    feed = re.search(r"device feed: (.*)\n", best[1])
+    tally = re.search(r"total_s=([\d.]+)", best[1])
+    print(json.dumps({"setting": st or "(default)", "wall_s": round(best[0], 3), "reads_per_s": round(args.reads / best[0]),
+                      "tally_phase_s": float(tally.group(1)) if tally else None, "same_tables": counts == ref_counts,
+                      "device_feed": feed.group(1) if feed else None}), flush=True)
 for p in tmp.iterdir():
     p.unlink()
 tmp.rmdir()
