@@ -128,6 +128,7 @@ def parse_args(argv=None):
     ap.add_argument("--scale-genome", type=float, default=1.0)
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the counter reduce even with one rank")
     ap.add_argument("--no-weak-leg", action="store_true", help="N > 1, strong: skip the additional weak-scaling measurement")
+    ap.add_argument("--force-weak-leg", action="store_true", help="run the weak-scaling companion leg even with one rank (test hook)")
     ap.add_argument("--e2e-reads", type=int, default=None,
                     help="reads of the file-to-tables leg (N=1; default: the configuration's count, bounded by free disk)")
     ap.add_argument("--no-e2e", action="store_true")
@@ -410,7 +411,7 @@ def main():
     strong_counters = m["counters"]
 
     # ---- N > 1: the weak-scaling companion measurement, in the same run ------------------------
-    if world > 1 and args.scaling == "strong" and not args.no_weak_leg:
+    if (world > 1 or args.force_weak_leg) and args.scaling == "strong" and not args.no_weak_leg:
         del wl
         torch.cuda.empty_cache()
         wcfg, wtotal, wslot0, wn = cfg_for("weak")

@@ -279,7 +279,9 @@ extern "C" int pssbam_engine_submit_bgzf(pssbam_engine *e, const void *comp, uin
     // room in the super-batch being assembled?  else launch it and turn to the other one
     {
         FeedAcc &cur = e->feed[e->cur_feed];
-        if (!cur.blocks.empty() && (cur.out_used + out_bytes > e->feed_out_target || cur.comp_used + comp_bytes + 32 > e->feed_comp_cap)) {
+        // (the first super-batch of a run is cut at a third of the target, so the device starts earlier)
+        const uint64_t target = e->inflated_bytes == 0 && !e->feed[e->cur_feed ^ 1].busy ? e->feed_out_target / 3 : e->feed_out_target;
+        if (!cur.blocks.empty() && (cur.out_used + out_bytes > target || cur.comp_used + comp_bytes + 32 > e->feed_comp_cap)) {
             rc = feed_flush(e);
             if (rc) return rc;
         }

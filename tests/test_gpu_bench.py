@@ -21,7 +21,8 @@ def _run(args, timeout=900):
 
 def test_bench_force_dist_one_rank_rccl():
     """--force-dist: a 1-rank RCCL communicator + dist.reduce of the bound counter tensor every step"""
-    pr = _run(["--force-dist", "--reads", "2000000", "--steps", "2", "--warmup", "1", "--no-e2e", "--cpu-sample", "200000"])
+    pr = _run(["--force-dist", "--force-weak-leg", "--reads", "2000000", "--steps", "2", "--warmup", "1", "--no-e2e", "--cpu-sample",
+               "200000"])
     assert pr.returncode == 0, pr.stderr[-3000:]
     line = [ln for ln in pr.stdout.splitlines() if ln.startswith("{")]
     assert len(line) == 1
@@ -30,6 +31,8 @@ def test_bench_force_dist_one_rank_rccl():
     assert d["stats_last_step"]["records"] == 2_000_000            # the reduce left rank 0's tables intact
     assert d["reduce_ms"] is not None and d["reduce_ms"] > 0
     assert d["per_rank"][0]["reads"] == 2_000_000
+    w = d["weak_scaling"]                                            # the N > 1 companion leg, forced here
+    assert w["scaling"] == "weak" and w["reads_per_gpu"] == 2_000_000 and w["value"] > 1e8 and w["reduce_ms"] > 0
     assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1.0
     assert d["cpu_baseline"]["cores"] == 1 and "bit-exact" in d["parity_check"]
 
