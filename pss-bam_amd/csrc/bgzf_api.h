@@ -206,9 +206,14 @@ static int feed_flush(pssbam_engine *e) {
     if ((rc = grow(&s.d_offs, &s.offs_cap, (size_t)(s.out_used / 36ull + 2ull * s.sub_first.size() + 16ull)))) return rc;
     if ((rc = grow(&s.d_nrecs, &s.nrecs_cap, s.sub_first.size()))) return rc;
     // every chunk of this super-batch has been issued on the copy streams: the engine's stream waits for them
-    if (!s.copies_done) HIP_TRY(hipEventCreateWithFlags(&s.copies_done, hipEventDisableTiming));
+    if (!s.copies_done) {
+        HIP_TRY(hipEventCreateWithFlags(&s.copies_done, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&s.copies_done2, hipEventDisableTiming));
+    }
     HIP_TRY(hipEventRecord(s.copies_done, e->copy_stream));
+    HIP_TRY(hipEventRecord(s.copies_done2, e->copy_stream2));
     HIP_TRY(hipStreamWaitEvent(e->stream, s.copies_done, 0));
+    HIP_TRY(hipStreamWaitEvent(e->stream, s.copies_done2, 0));
     HIP_TRY(hipMemcpyAsync(s.d_blocks, s.blocks.data(), nb * sizeof(pssbam_bgzf_block), hipMemcpyHostToDevice, e->stream));
     hipEvent_t ev0 = take_event(e), ev1 = take_event(e);
     if (!ev0 || !ev1) return fail(PSSBAM_EHIP, "hipEventCreate failed");
@@ -257,6 +262,52 @@ static int feed_flush(pssbam_engine *e) {
     return PSSBAM_OK;
 }
 
+// appends blocks[b0, b1) of a chunk (and their compressed bytes) to the super-batch being assembled
+static int feed_append(pssbam_engine *e, const uint8_t *comp, const pssbam_bgzf_block *blocks, uint32_t b0, uint32_t b1,
+                       uint32_t first_record_offset, hipStream_t cs) {
+    FeedAcc &s = e->feed[e->cur_feed];
+    int rc;
+    if (s.busy) {   // its previous super-batch must have been consumed before its buffers are overwritten
+        HIP_TRY(hipEventSynchronize(s.consumed));
+        s.busy = false;
+    }
+    if (!s.d_comp) {
+        s.comp_cap = (size_t)e->feed_comp_cap;
+        HIP_TRY(hipMalloc(&s.d_comp, s.comp_cap + 64));
+    }
+    const uint64_t byte0 = blocks[b0].in_off & ~15ull, byte1 = blocks[b1 - 1].in_off + blocks[b1 - 1].in_len;
+    const uint64_t out_bytes = blocks[b1 - 1].out_off + blocks[b1 - 1].isize - blocks[b0].out_off;
+    if (s.out_cap < s.out_used + out_bytes + 8192) {
+        if (s.out_used) return fail(PSSBAM_ESTATE, "output buffer of the super-batch cannot grow while it holds blocks");
+        const uint64_t need_out = std::max<uint64_t>(e->feed_out_target, out_bytes) + (2ull << 30) + 8192;
+        if ((rc = grow(&s.d_out, &s.out_cap, (size_t)need_out))) return rc;
+    }
+    // blocks: in_off -> into d_comp, out_off -> into d_out; a new tally sub-batch where the record
+    // bytes would pass 3.5 GiB or where bytes must be skipped in front of the first record
+    const uint64_t comp_at = (s.comp_used + 15ull) & ~15ull;
+    if (comp_at + (byte1 - byte0) + 32 > s.comp_cap) return fail(PSSBAM_ESTATE, "compressed bytes of the super-batch exceed their buffer");
+    for (uint32_t i = b0; i < b1; i++) {
+        pssbam_bgzf_block b = blocks[i];
+        const bool new_sub = s.sub_first.empty() || (i == b0 && first_record_offset) || s.sub_bytes + b.isize > FEED_SUB_MAX;
+        if (new_sub) {
+            s.out_used = (s.out_used + 255ull) & ~255ull;   // a tally launch wants its records 16-byte aligned
+            s.sub_first.push_back((uint32_t)s.blocks.size());
+            s.sub_skip.push_back(i == b0 ? first_record_offset : 0u);
+            s.sub_bytes = 0;
+        }
+        b.in_off = b.in_off - byte0 + comp_at;
+        b.out_off = s.out_used;
+        b.status = 0;
+        s.out_used += b.isize;
+        s.sub_bytes += b.isize;
+        s.blocks.push_back(b);
+    }
+    HIP_TRY(hipMemcpyAsync(s.d_comp + comp_at, comp + byte0, byte1 - byte0, hipMemcpyHostToDevice, cs));
+    s.comp_used = comp_at + (byte1 - byte0);
+    e->h2d_bytes += byte1 - byte0;
+    return PSSBAM_OK;
+}
+
 extern "C" int pssbam_engine_submit_bgzf(pssbam_engine *e, const void *comp, uint64_t comp_bytes, const pssbam_bgzf_block *blocks,
                                          uint32_t n_blocks, uint32_t first_record_offset, uint64_t *ticket) {
     int rc = check_ready(e);
@@ -273,62 +324,49 @@ extern "C" int pssbam_engine_submit_bgzf(pssbam_engine *e, const void *comp, uin
     HIP_TRY(hipSetDevice(e->device));
     if (!e->d_feed_flags) {
         if (getenv("PSSBAM_FEED_SUPER_BYTES")) e->feed_out_target = std::max<uint64_t>(1ull << 20, strtoull(getenv("PSSBAM_FEED_SUPER_BYTES"), nullptr, 10));
+        // the inflate kernel keeps 3 waves x 64 lanes per CU busy, a block per lane, and blocks take about the
+        // same time: a super-batch of a whole number of "rounds" of blocks wastes no partial round
+        const uint64_t lanes = (uint64_t)e->n_cu * 3ull * 64ull;
+        const uint64_t rounds = std::max<uint64_t>(1, e->feed_out_target / (lanes * 65280ull));
+        e->feed_block_target = getenv("PSSBAM_FEED_SUPER_BYTES") && e->feed_out_target < lanes * 65280ull ? 0xFFFFFFFFull : rounds * lanes;
         HIP_TRY(hipMalloc(&e->d_feed_flags, sizeof(uint32_t)));
         HIP_TRY(hipMemsetAsync(e->d_feed_flags, 0, sizeof(uint32_t), e->stream));
     }
-    // room in the super-batch being assembled?  else launch it and turn to the other one
-    {
+    hipStream_t cs = (e->ticket_seq & 1u) ? e->copy_stream2 : e->copy_stream;
+    uint32_t b0 = 0;
+    while (b0 < n_blocks) {
         FeedAcc &cur = e->feed[e->cur_feed];
-        // (the first super-batch of a run is cut at a third of the target, so the device starts earlier)
-        const uint64_t target = e->inflated_bytes == 0 && !e->feed[e->cur_feed ^ 1].busy ? e->feed_out_target / 3 : e->feed_out_target;
-        if (!cur.blocks.empty() && (cur.out_used + out_bytes > target || cur.comp_used + comp_bytes + 32 > e->feed_comp_cap)) {
+        // (the first super-batch of a run is cut at a round of blocks / a third of the bytes, so the device starts earlier)
+        const bool first = e->inflated_bytes == 0 && !e->feed[e->cur_feed ^ 1].busy;
+        const uint64_t byte_target = first ? e->feed_out_target / 3 : e->feed_out_target;
+        const uint64_t block_target = e->feed_block_target == 0xFFFFFFFFull ? 0xFFFFFFFFull
+                                      : first ? std::max<uint64_t>(e->feed_block_target / 3 / ((uint64_t)e->n_cu * 192ull), 1) * ((uint64_t)e->n_cu * 192ull)
+                                              : e->feed_block_target;
+        // how many of the remaining blocks still fit
+        uint32_t b1 = b0;
+        const uint64_t comp0 = blocks[b0].in_off & ~15ull, out0 = blocks[b0].out_off;
+        while (b1 < n_blocks && cur.blocks.size() + (b1 - b0) < block_target &&
+               cur.out_used + (blocks[b1].out_off + blocks[b1].isize - out0) + 512 <= byte_target + (1ull << 30) &&
+               cur.comp_used + (blocks[b1].in_off + blocks[b1].in_len - comp0) + 64 <= e->feed_comp_cap)
+            b1++;
+        if (b1 == b0) {
+            if (cur.blocks.empty()) return fail(PSSBAM_EINVAL, "a single BGZF block does not fit the feed buffers");
+            rc = feed_flush(e);
+            if (rc) return rc;
+            continue;
+        }
+        rc = feed_append(e, (const uint8_t *)comp, blocks, b0, b1, b0 == 0 ? first_record_offset : 0u, cs);
+        if (rc) return rc;
+        b0 = b1;
+        if (e->feed[e->cur_feed].blocks.size() >= block_target || e->feed[e->cur_feed].out_used >= byte_target) {
             rc = feed_flush(e);
             if (rc) return rc;
         }
     }
-    FeedAcc &s = e->feed[e->cur_feed];
-    if (s.busy) {   // its previous super-batch must have been consumed before its buffers are overwritten
-        HIP_TRY(hipEventSynchronize(s.consumed));
-        s.busy = false;
-    }
-    if (!s.d_comp) {
-        s.comp_cap = (size_t)e->feed_comp_cap;
-        HIP_TRY(hipMalloc(&s.d_comp, s.comp_cap + 64));
-    }
-    const uint64_t need_out = std::max<uint64_t>(e->feed_out_target, s.out_used + out_bytes) + (2ull << 30) + 4096;
-    if (s.out_cap < s.out_used + out_bytes + 4096) {
-        if (s.out_used) return fail(PSSBAM_ESTATE, "output buffer of the super-batch cannot grow while it holds blocks");
-        if ((rc = grow(&s.d_out, &s.out_cap, (size_t)need_out))) return rc;
-    }
-    // blocks: in_off -> into d_comp, out_off -> into d_out; a new tally sub-batch where the record
-    // bytes would pass 3.5 GiB or where bytes must be skipped in front of the first record
-    const uint64_t comp_at = (s.comp_used + 15ull) & ~15ull;
-    for (uint32_t i = 0; i < n_blocks; i++) {
-        pssbam_bgzf_block b = blocks[i];
-        const bool new_sub = s.sub_first.empty() || (i == 0 && first_record_offset) || s.sub_bytes + b.isize > FEED_SUB_MAX;
-        if (new_sub) {
-            s.out_used = (s.out_used + 255ull) & ~255ull;   // a tally launch wants its records 16-byte aligned
-            s.sub_first.push_back((uint32_t)s.blocks.size());
-            s.sub_skip.push_back(i == 0 ? first_record_offset : 0u);
-            s.sub_bytes = 0;
-        }
-        b.in_off += comp_at;
-        b.out_off = s.out_used;
-        b.status = 0;
-        s.out_used += b.isize;
-        s.sub_bytes += b.isize;
-        s.blocks.push_back(b);
-    }
-    // the chunk's bytes over PCIe, alternating between the two copy streams
-    hipStream_t cs = (e->ticket_seq & 1u) ? e->copy_stream2 : e->copy_stream;
-    HIP_TRY(hipMemcpyAsync(s.d_comp + comp_at, comp, comp_bytes, hipMemcpyHostToDevice, cs));
     hipEvent_t done = nullptr;
     if (!e->feed_event_pool.empty()) { done = e->feed_event_pool.back(); e->feed_event_pool.pop_back(); }
     else HIP_TRY(hipEventCreateWithFlags(&done, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(done, cs));
-    if (cs == e->copy_stream2) HIP_TRY(hipStreamWaitEvent(e->copy_stream, done, 0));   // flush waits on copy_stream alone
-    s.comp_used = comp_at + comp_bytes;
-    e->h2d_bytes += comp_bytes;
     const uint64_t t = ++e->ticket_seq;
     e->feed_copies.emplace_back(t, done);
     if (ticket) *ticket = t;

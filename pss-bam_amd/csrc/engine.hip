@@ -94,7 +94,7 @@ struct FeedAcc {  // one super-batch of compressed blocks: assembled chunk by ch
     size_t offs_cap = 0;
     uint32_t *d_nrecs = nullptr;
     size_t nrecs_cap = 0;
-    hipEvent_t consumed = nullptr, copies_done = nullptr;
+    hipEvent_t consumed = nullptr, copies_done = nullptr, copies_done2 = nullptr;
     bool busy = false;
 };
 
@@ -139,6 +139,7 @@ struct pssbam_engine {
     FeedAcc feed[2];
     int cur_feed = 0;
     uint64_t feed_out_target = 12ull << 30, feed_comp_cap = 4ull << 30;   // per super-batch
+    uint64_t feed_block_target = 0;   // blocks per super-batch: a whole number of rounds of the inflate kernel's lanes
     std::vector<std::pair<uint64_t, hipEvent_t>> feed_copies;             // (ticket, copy-complete event) of submits
     std::vector<hipEvent_t> feed_event_pool;
     uint32_t *d_feed_flags = nullptr;
@@ -284,6 +285,7 @@ extern "C" void pssbam_engine_destroy(pssbam_engine *e) {
         if (s.d_nrecs) (void)hipFree(s.d_nrecs);
         if (s.consumed) (void)hipEventDestroy(s.consumed);
         if (s.copies_done) (void)hipEventDestroy(s.copies_done);
+        if (s.copies_done2) (void)hipEventDestroy(s.copies_done2);
     }
     for (auto &p : e->feed_copies) (void)hipEventDestroy(p.second);
     for (hipEvent_t ev : e->feed_event_pool) (void)hipEventDestroy(ev);
