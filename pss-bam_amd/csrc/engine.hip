@@ -480,9 +480,10 @@ static int prep_kernel(pssbam_engine *e, int variant, K kernel, uint32_t lds_byt
 // reads (through QUAL[0]; the whole record when the -R filter walks the aux fields) is in LDS
 // for typical records: sampled from the first records of a block.  Records that need more take
 // the kernel's out-of-line global-memory path, so this is a performance choice only.
-static uint32_t sample_prefix_pieces(const uint8_t *bytes, uint64_t nbytes, bool whole_record) {
+// (returns the largest prefix, in bytes, any sampled record needs)
+static uint64_t sample_prefix_need(const uint8_t *bytes, uint64_t nbytes, bool whole_record, int max_records = 4096) {
     uint64_t o = 0, need_max = 64;
-    for (int n = 0; n < 4096 && o + 36 <= nbytes; n++) {
+    for (int n = 0; n < max_records && o + 36 <= nbytes; n++) {
         uint32_t bs, l_seq;
         memcpy(&bs, bytes + o, 4);
         if (bs < 32 || o + 4 + (uint64_t)bs > nbytes) break;
@@ -495,6 +496,10 @@ static uint32_t sample_prefix_pieces(const uint8_t *bytes, uint64_t nbytes, bool
         need_max = std::max(need_max, need);
         o += 4 + (uint64_t)bs;
     }
+    return need_max;
+}
+
+static uint32_t pieces_for(uint64_t need_max) {
     uint64_t pieces = (need_max + 15 + 15) / 16;  // + worst-case misalignment of the record start
     // records sit pieces*16 bytes apart in LDS: an even piece count puts every record start of a
     // wave on few banks (pieces = 8 -> all on one); an odd count spreads them over 8
@@ -507,7 +512,7 @@ static uint32_t sample_prefix_pieces(const uint8_t *bytes, uint64_t nbytes, bool
 // bytes into the block.
 static int launch_tally(pssbam_engine *e, const uint8_t *d_recs, uint64_t nbytes, const uint32_t *d_offs,
                         uint32_t n_records, const uint8_t *host_sample, uint64_t host_sample_bytes,
-                        const uint32_t *d_n_recs = nullptr, uint64_t sample_off = 0) {
+                        const uint32_t *d_n_recs = nullptr, uint64_t sample_off = 0, const uint32_t *host_offsets = nullptr) {
     if (!n_records) return PSSBAM_OK;
     const pssbam_config &c = e->cfg;
     TallyParams P{};
@@ -575,14 +580,37 @@ static int launch_tally(pssbam_engine *e, const uint8_t *d_recs, uint64_t nbytes
         const uint64_t avg = std::max<uint64_t>(40, nbytes / n_records);
         uint32_t pieces;
         if (host_sample) {
-            pieces = sample_prefix_pieces(host_sample, host_sample_bytes, e->has_rg);
+            // three regions of the block (start, middle, end: 1400 records each), found through the
+            // caller's offset index -- a block whose later records are longer than its first ones must
+            // not silently fall onto the one-lane path (stats.slow_path)
+            uint64_t need = sample_prefix_need(host_sample, host_sample_bytes, e->has_rg, 1400);
+            if (host_offsets && n_records > 4200u) {
+                const uint32_t mid = host_offsets[n_records / 2], late = host_offsets[n_records - 1400u];
+                need = std::max(need, sample_prefix_need(host_sample + mid, host_sample_bytes - mid, e->has_rg, 1400));
+                need = std::max(need, sample_prefix_need(host_sample + late, host_sample_bytes - late, e->has_rg, 1400));
+            }
+            pieces = pieces_for(need);
         } else {
             if (!e->dev_pieces || (!d_n_recs && (avg * 8 < e->dev_pieces_avg * 7 || avg * 7 > e->dev_pieces_avg * 8))) {
                 sample_off = std::min<uint64_t>(sample_off, nbytes);
                 std::vector<uint8_t> head((size_t)std::min<uint64_t>(nbytes - sample_off, 1024 * 1024));
                 HIP_TRY(hipMemcpyAsync(head.data(), d_recs + sample_off, head.size(), hipMemcpyDeviceToHost, e->stream));
                 HIP_TRY(hipStreamSynchronize(e->stream));
-                e->dev_pieces = sample_prefix_pieces(head.data(), head.size(), e->has_rg);
+                uint64_t need = sample_prefix_need(head.data(), head.size(), e->has_rg);
+                if (!d_n_recs && n_records > 8192u) {   // device-resident block with a known count: its middle and end too
+                    uint32_t at[2] = {0, 0};
+                    HIP_TRY(hipMemcpyAsync(&at[0], d_offs + n_records / 2, 4, hipMemcpyDeviceToHost, e->stream));
+                    HIP_TRY(hipMemcpyAsync(&at[1], d_offs + (n_records - 2048u), 4, hipMemcpyDeviceToHost, e->stream));
+                    HIP_TRY(hipStreamSynchronize(e->stream));
+                    for (int k = 0; k < 2; k++) {
+                        if ((uint64_t)at[k] >= nbytes) continue;
+                        head.resize((size_t)std::min<uint64_t>(nbytes - at[k], 512 * 1024));
+                        HIP_TRY(hipMemcpyAsync(head.data(), d_recs + at[k], head.size(), hipMemcpyDeviceToHost, e->stream));
+                        HIP_TRY(hipStreamSynchronize(e->stream));
+                        need = std::max(need, sample_prefix_need(head.data(), head.size(), e->has_rg, 2048));
+                    }
+                }
+                e->dev_pieces = pieces_for(need);
                 e->dev_pieces_avg = avg;
             }
             pieces = e->dev_pieces;
@@ -740,7 +768,7 @@ extern "C" int pssbam_engine_submit_async(pssbam_engine *e, const void *records,
     s.timed = true;
     e->h2d_bytes += nbytes + ((uint64_t)n_records + 1) * sizeof(uint32_t);
     HIP_TRY(hipStreamWaitEvent(e->stream, s.copied, 0));
-    rc = launch_tally(e, s.d_recs, nbytes, s.d_offs, n_records, (const uint8_t *)records, nbytes);
+    rc = launch_tally(e, s.d_recs, nbytes, s.d_offs, n_records, (const uint8_t *)records, nbytes, nullptr, 0, offsets);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(s.consumed, e->stream));
     s.busy = true;

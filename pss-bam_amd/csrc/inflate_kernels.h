@@ -63,19 +63,26 @@ struct LaneLds {  // this lane's view of the interleaved table
 };
 
 struct BitReader {
-    const uint32_t *p;     // next aligned dword
+    const uint32_t *p;     // next aligned dword to fetch
     const uint32_t *end;   // first dword that must not be read
     uint64_t buf;
     uint32_t cnt;          // valid bits in buf
+    uint32_t ahead;        // the dword at p[-1], fetched one refill early
     uint64_t consumed;     // bits handed out
     uint64_t limit;        // payload bits
 
+    // The dword that enters the bit buffer was requested at the PREVIOUS refill: its wait only
+    // covers memory operations older than that request (vmcnt retires in order), so a refill no
+    // longer drains the stores the lane has issued since.
+    __device__ __forceinline__ void fetch() {
+        ahead = p < end ? *p : 0u;
+        p++;
+    }
     __device__ __forceinline__ void refill() {
         if (cnt <= 32u) {
-            const uint32_t w = p < end ? *p : 0u;
-            p++;
-            buf |= (uint64_t)w << cnt;
+            buf |= (uint64_t)ahead << cnt;
             cnt += 32u;
+            fetch();
         }
     }
     __device__ __forceinline__ uint32_t peek15() const { return __brev((uint32_t)buf) >> 17; }  // first-read bit = MSB
@@ -139,6 +146,12 @@ __device__ __forceinline__ uint4 load_u128(const uint8_t *p) {
     return v;
 }
 __device__ __forceinline__ void store_u128(uint8_t *p, uint4 v) { __builtin_memcpy(p, &v, 16); }
+// the low n (< 8) bytes of v, without a loop and without loads
+__device__ __forceinline__ void store_tail(uint8_t *p, uint64_t v, uint32_t n) {
+    if (n & 4u) { const uint32_t w = (uint32_t)v; __builtin_memcpy(p, &w, 4); p += 4; v >>= 32; }
+    if (n & 2u) { const uint16_t h = (uint16_t)v; __builtin_memcpy(p, &h, 2); p += 2; v >>= 16; }
+    if (n & 1u) *p = (uint8_t)v;
+}
 
 // One BGZF block by one lane.  Returns INF_*.
 __device__ uint32_t inflate_block(const uint8_t *comp, uint64_t comp_bytes, const BgzfBlock &b, uint8_t *outbuf, const LaneLds &t) {
@@ -153,6 +166,7 @@ __device__ uint32_t inflate_block(const uint8_t *comp, uint64_t comp_bytes, cons
         br.cnt = 0;
         br.consumed = 0;
         br.limit = (uint64_t)b.in_len * 8ull;
+        br.fetch();
         br.refill();
         const uint32_t skip = 8u * (uint32_t)(a & 3ull);
         br.buf >>= skip;
@@ -337,39 +351,50 @@ __device__ uint32_t inflate_block(const uint8_t *comp, uint64_t comp_bytes, cons
                 if (len > isize - pos) return INF_OVERRUN;
                 uint8_t *dst = out + pos;
                 pos += len;
+                // (every path below issues its loads first and its stores last: a store is never waited
+                //  for, a load is waited for once; the over-reads stay inside the output buffer's slack)
                 if (dist >= 64u) {
                     // far matches (the usual case in a BAM: the previous record): 32 bytes per step, and the
                     // loads of step i+1 are issued BEFORE the stores of step i (they cannot overlap them:
                     // src + 64 <= dst) -- the wait for a load then does not include the younger stores
-                    // (vmcnt retires in order), so a step costs one load round trip, not a store + a load
                     const uint8_t *src = dst - dist;
-                    if (len >= 32u) {
-                        uint4 a = load_u128(src), b = load_u128(src + 16);
-                        while (len >= 64u) {
-                            const uint4 na = load_u128(src + 32), nb = load_u128(src + 48);
-                            store_u128(dst, a);
-                            store_u128(dst + 16, b);
-                            a = na; b = nb;
-                            dst += 32; src += 32; len -= 32u;
-                        }
+                    uint4 a = load_u128(src), b = load_u128(src + 16);
+                    while (len >= 64u) {
+                        const uint4 na = load_u128(src + 32), nb = load_u128(src + 48);
                         store_u128(dst, a);
                         store_u128(dst + 16, b);
+                        a = na; b = nb;
                         dst += 32; src += 32; len -= 32u;
                     }
-                    while (len >= 8u) { store_u64(dst, load_u64(src)); dst += 8; src += 8; len -= 8u; }
-                    for (uint32_t i = 0; i < len; i++) dst[i] = src[i];
+                    if (len >= 32u) {
+                        const uint4 na = load_u128(src + 32), nb = load_u128(src + 48);   // (src + 64 <= dst)
+                        store_u128(dst, a);
+                        store_u128(dst + 16, b);
+                        a = na; b = nb;
+                        dst += 32; src += 32; len -= 32u;
+                    }
+                    // 0..31 bytes left, all of them in (a, b)
+                    if (len & 16u) { store_u128(dst, a); dst += 16; a = b; }
+                    uint64_t t = (uint64_t)a.x | ((uint64_t)a.y << 32);
+                    if (len & 8u) { store_u64(dst, t); dst += 8; t = (uint64_t)a.z | ((uint64_t)a.w << 32); }
+                    store_tail(dst, t, len & 7u);
                 } else if (dist >= 8u) {
                     const uint8_t *src = dst - dist;
                     while (len >= 8u) { store_u64(dst, load_u64(src)); dst += 8; src += 8; len -= 8u; }
-                    for (uint32_t i = 0; i < len; i++) dst[i] = src[i];
+                    if (len) store_tail(dst, load_u64(src), len);   // (src + len <= dst: the bytes used are old ones)
                 } else {
                     // periodic pattern of period `dist` in a register: no load-after-store chain
-                    uint64_t pat = 0;
-                    for (uint32_t i = 0; i < dist; i++) pat |= (uint64_t)dst[(int)i - (int)dist] << (8u * i);
+                    uint64_t pat;
+                    if (pos - len >= 8u) pat = load_u64(dst - 8) >> (8u * (8u - dist));   // the last `dist` bytes written
+                    else {
+                        pat = 0;
+                        for (uint32_t i = 0; i < dist; i++) pat |= (uint64_t)dst[(int)i - (int)dist] << (8u * i);
+                    }
+                    pat &= dist >= 8u ? ~0ull : (1ull << (8u * dist)) - 1ull;
                     for (uint32_t w = dist; w < 8u; w <<= 1) pat |= pat << (8u * w);
                     const uint32_t step = (8u / dist) * dist;   // whole periods per 8-byte store
                     while (len >= 8u) { store_u64(dst, pat); dst += step; len -= step; }
-                    for (uint32_t i = 0; i < len; i++) dst[i] = (uint8_t)(pat >> (8u * i));
+                    store_tail(dst, pat, len);
                 }
             }
             if (br.overrun()) return INF_TRUNCATED;

@@ -27,7 +27,15 @@
 #include <stdlib.h>
 #include <string.h>
 #include <sys/stat.h>
+#include <time.h>
 #include <unistd.h>
+
+static double mono_s(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + ts.tv_nsec * 1e-9;
+}
 
 #define MAX_STAGE 40
 #define BLOCKS_PER_SCAN 65536u
@@ -158,7 +166,9 @@ int run_device_feed(pssbam_engine *const *eng, int n_gpus, const char *path, siz
 #define RETIRE()                                                                                         \
     do {                                                                                                 \
         const int q = fifo_head;                                                                         \
+        const double tr_ = mono_s();                                                                     \
         if (pssbam_engine_wait_bgzf_copied(eng[fifo[q].g], fifo[q].ticket)) goto done;                    \
+        t_wait_copy += mono_s() - tr_;                                                                   \
         stage_t *rs = &L.st[fifo[q].chunk % L.n_st];                                                      \
         if (--pending_of_chunk[fifo[q].chunk % L.n_st] == 0) {                                            \
             pthread_mutex_lock(&L.mu);                                                                    \
@@ -171,21 +181,26 @@ int run_device_feed(pssbam_engine *const *eng, int n_gpus, const char *path, siz
         fifo_len--;                                                                                       \
     } while (0)
 
+    double t_wait_load = 0, t_wait_copy = 0, t_scan = 0, t_submit = 0;
     size_t pos = 0;                /* file offset of the next BGZF block */
     size_t skip = header_bytes;    /* inflated bytes still to skip in front of the first record */
     uint64_t n_submits = 0;
     for (long k = 0; k < L.n_chunks; k++) {
         stage_t *s = &L.st[k % L.n_st];
+        const double tw = mono_s();
         pthread_mutex_lock(&L.mu);
         while (s->loaded != k) pthread_cond_wait(&L.cv, &L.mu);
         pthread_mutex_unlock(&L.mu);
+        t_wait_load += mono_s() - tw;
         if (s->io_error) { fprintf(stderr, "Error: %s: read failed\n", path); goto done; }
         const size_t win0 = (size_t)k * L.W, win_end = win0 + L.W; /* blocks STARTING in [win0, win_end) are this chunk's */
         int submitted_from_chunk = 0;
         while (pos < win_end && pos < L.file_size) {
             if (pos < win0) { fprintf(stderr, "Error: %s: BGZF block chain lost\n", path); goto done; }
             uint64_t consumed = 0, inflated = 0;
+            const double ts = mono_s();
             const int64_t n = pssbam_bgzf_scan(s->buf + (pos - win0), s->len - (pos - win0), blocks, BLOCKS_PER_SCAN, &consumed, &inflated);
+            t_scan += mono_s() - ts;
             if (n < 0) { fprintf(stderr, "Error: %s: %s\n", path, pssbam_last_error()); goto done; }
             if (n == 0) {
                 if (win0 + s->len >= L.file_size) { fprintf(stderr, "Error: %s: truncated BGZF block at end of file\n", path); goto done; }
@@ -218,11 +233,13 @@ int run_device_feed(pssbam_engine *const *eng, int n_gpus, const char *path, siz
                 const uint64_t end_in = blocks[j - 1].in_off + blocks[j - 1].in_len;
                 const int g = (int)((n_submits / (uint64_t)run) % (uint64_t)n_gpus);
                 uint64_t ticket = 0;
+                const double tsub = mono_s();
                 if (pssbam_engine_submit_bgzf(eng[g], s->buf + chunk_rel + base_in, end_in - base_in, grp, (uint32_t)(j - i), (uint32_t)skip,
                                               &ticket)) {
                     fprintf(stderr, "Error: GPU engine: %s\n", pssbam_last_error());
                     goto done;
                 }
+                t_submit += mono_s() - tsub;
                 skip = 0;
                 n_submits++;
                 fs->compressed_bytes += end_in - base_in;
@@ -265,6 +282,9 @@ int run_device_feed(pssbam_engine *const *eng, int n_gpus, const char *path, siz
                 (unsigned long long)n_submits, fs->compressed_bytes * 1e-9, fs->inflated_bytes * 1e-9, fs->inflate_ms * 1e-3,
                 fs->inflate_ms > 0 ? fs->inflated_bytes * 1e-6 / fs->inflate_ms : 0.0, n_th, L.n_st, L.W >> 20,
                 fs->fallback ? "; records cross BGZF blocks -> host reader" : "");
+    if (verbose)
+        fprintf(stderr, "[pssbam] device feed, this thread: waiting for loaders %.3f, block-header walk %.3f, submit (incl. waiting for a "
+                        "free super-batch) %.3f, waiting for copies %.3f s\n", t_wait_load, t_scan, t_submit, t_wait_copy);
     rc = 0;
 done:
     pthread_mutex_lock(&L.mu);

@@ -123,6 +123,9 @@ int main(int argc, char *argv[])
     if (getenv("PSSBAM_STATS")) {
         static const char *nm[] = {"records", "rg_dropped", "parse_skip", "no_contig", "pss_ok", "pss_filtered"};
         for (int i = 0; i < 6; i++) fprintf(stderr, "[pssbam] %s=%llu\n", nm[i], (unsigned long long)res.stats[i]);
+        fprintf(stderr, "[pssbam] slow_path=%llu%s\n", (unsigned long long)res.stats[PSSBAM_ST_SLOW_PATH],
+                res.stats[PSSBAM_ST_SLOW_PATH] * 100 > res.stats[PSSBAM_ST_RECORDS]
+                    ? "  (more than 1 % of the records were longer than the staged prefix and took the one-lane path: slower, same tables)" : "");
         fprintf(stderr, "[pssbam] gpus=%d inflate_s=%.3f total_s=%.3f\n", res.n_gpus, res.inflate_s, res.total_s);
     }
     if (frontend_fast_exit) { /* nothing left to do but to hand the memory back: let the OS */

@@ -287,3 +287,43 @@ def test_kmer_lengths_beyond_twelve(pkg, oracle, tmp_path):
         eng.close()
     finally:
         oracle.free_genome(g)
+
+
+def test_prefix_sample_covers_late_long_records(pkg, oracle, tmp_path):
+    """the tiled kernels stage a record prefix whose size is sampled per block; a block whose LATER
+    records are longer than its first ones must still be sampled right (start, middle and end are
+    looked at), so nothing lands on the one-lane slow path -- host blocks and device-resident blocks"""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")          # device buffers for the submit_device leg, straight from the HIP runtime
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
+    contigs, refs, recs = tl.fuzz_dataset(2024, 12000, contig_lens=(30000, 8000))
+    recs = sorted(recs, key=lambda r: len(r.seq))            # short reads first, 250-bp reads last
+    fa, sam = tmp_path / "g.fa", tmp_path / "a.sam"
+    tl.write_fasta(fa, contigs)
+    tl.write_sam(sam, refs, recs)
+    g = oracle.load_genome(fa)
+    po = tl.PssOpts(region_len=20)
+    wf, wr, st = oracle.pss(g, sam, po)
+    oracle.free_genome(g)
+    raw = tl.raw_records(refs, recs)
+    offs = pkg.index_records(raw)
+    for mode in ("host", "device"):
+        eng = pkg.Engine(pss=_pss_dict(po), kernel=pkg.KERNEL_TILED)
+        eng.set_genome_arrays(tl.loaded_contigs(contigs))
+        eng.set_references([n for n, _ in refs])
+        if mode == "host":
+            eng.submit(raw, offs)
+        else:
+            padded = np.concatenate([raw, np.zeros(64, dtype=np.uint8)])
+            d_r, d_o = C.c_void_p(), C.c_void_p()
+            assert hip.hipMalloc(C.byref(d_r), padded.size) == 0 and hip.hipMalloc(C.byref(d_o), offs.size * 4) == 0
+            assert hip.hipMemcpy(d_r, padded.ctypes.data, padded.size, 1) == 0 and hip.hipMemcpy(d_o, offs.ctypes.data, offs.size * 4, 1) == 0
+            eng.submit_device(d_r.value, raw.size, d_o.value, offs.size - 1)
+        got = eng.finish()
+        eng.close()
+        if mode == "device":
+            hip.hipFree(d_r), hip.hipFree(d_o)
+        _check_pss(got, wf, wr, st)
+        assert got.stats["slow_path"] == 0, (mode, got.stats)
