@@ -247,6 +247,9 @@ int pssbam_engine_wait_bgzf_copied(pssbam_engine *e, uint64_t ticket);
 #define PSSBAM_FEED_RAGGED 2u      /* records cross BGZF blocks: use the host reader for this file     */
 #define PSSBAM_FEED_BAD_RECORD 4u  /* an alignment record with block_size < 32                        */
 int pssbam_engine_feed_status(pssbam_engine *e, uint32_t *flags, double *inflate_ms, uint64_t *inflated_bytes);
+/* Optional: allocates the feed's device buffers (~17 GB) for `device` ahead of time, e.g. from a helper
+ * thread while the FASTA loads; the first engine on that device that feeds compressed blocks takes them. */
+int pssbam_feed_reserve(int device);
 
 /* Test / tool convenience: host BGZF bytes in, inflated bytes out (out may be NULL), kernels timed
  * with HIP events (*kernel_ms = best of `repeats` runs of inflate + CRC). */

@@ -180,6 +180,12 @@ extern "C" int pssbam_bgzf_inflate_host(int device, const void *bgzf, uint64_t n
 // flushed: one inflate launch + one CRC launch over all blocks, then per < 4 GiB sub-batch (the
 // tally kernels index records with u32 offsets) the record index and the tally.  Two super-batches
 // alternate, so chunks keep arriving over PCIe while the previous one is inflated.
+static double feed_now() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + ts.tv_nsec * 1e-9;
+}
+
 template <class T>
 static int grow(T **ptr, size_t *cap, size_t need, size_t elem = sizeof(T)) {
     if (*cap >= need) return PSSBAM_OK;
@@ -192,10 +198,57 @@ static int grow(T **ptr, size_t *cap, size_t need, size_t elem = sizeof(T)) {
 
 static constexpr uint64_t FEED_SUB_MAX = (3584ull << 20);   // records per tally launch: below 4 GiB
 
+// Device buffers of the feed can be reserved ahead of the first submit (pssbam_feed_reserve, from a
+// helper thread while the caller still loads its FASTA): allocating ~17 GB takes from a millisecond
+// to a second depending on what the driver has to reclaim.
+namespace {
+struct FeedReserve { uint8_t *comp[2] = {nullptr, nullptr}, *out[2] = {nullptr, nullptr}; size_t comp_cap = 0, out_cap = 0; };
+FeedReserve g_feed_reserve[64];
+std::mutex g_feed_reserve_mu;
+}  // namespace
+
+extern "C" int pssbam_feed_reserve(int device) {
+    if (device < 0 || device >= 64) return fail(PSSBAM_EINVAL, "device %d out of range", device);
+    HIP_TRY(hipSetDevice(device));
+    FeedReserve r;
+    r.comp_cap = (size_t)FEED_COMP_CAP;
+    r.out_cap = (size_t)(FEED_OUT_TARGET + FEED_OUT_SLACK);
+    for (int k = 0; k < 2; k++) {
+        HIP_TRY(hipMalloc(&r.comp[k], r.comp_cap + 64));
+        HIP_TRY(hipMalloc(&r.out[k], r.out_cap));
+    }
+    std::lock_guard<std::mutex> lk(g_feed_reserve_mu);
+    if (g_feed_reserve[device].comp[0]) {   // somebody was faster: keep theirs
+        for (int k = 0; k < 2; k++) { (void)hipFree(r.comp[k]); (void)hipFree(r.out[k]); }
+        return PSSBAM_OK;
+    }
+    g_feed_reserve[device] = r;
+    return PSSBAM_OK;
+}
+
+// takes one (comp, out) pair from the device's reserve, if there is one of the wanted size
+static bool feed_take_reserved(int device, size_t comp_cap, uint8_t **comp, uint8_t **out, size_t *out_cap) {
+    if (device < 0 || device >= 64) return false;
+    std::lock_guard<std::mutex> lk(g_feed_reserve_mu);
+    FeedReserve &r = g_feed_reserve[device];
+    if (r.comp_cap != comp_cap) return false;
+    for (int k = 0; k < 2; k++)
+        if (r.comp[k]) {
+            *comp = r.comp[k];
+            *out = r.out[k];
+            *out_cap = r.out_cap;
+            r.comp[k] = r.out[k] = nullptr;
+            return true;
+        }
+    return false;
+}
+
 static int feed_flush(pssbam_engine *e) {
     FeedAcc &s = e->feed[e->cur_feed];
     if (s.blocks.empty()) return PSSBAM_OK;
     int rc;
+    const double t_flush0 = feed_now();
+    struct FlushTimer { pssbam_engine *e; double t0; ~FlushTimer() { e->feed_t_flush += feed_now() - t0; } } flush_timer{e, t_flush0};
     const size_t nb = s.blocks.size();
     if (nb > 0xFFFFFFF0ull) return fail(PSSBAM_EINVAL, "too many BGZF blocks in one super-batch");
     size_t bc = s.blocks_cap, bc2 = s.blocks_cap, bc3 = s.blocks_cap;
@@ -268,20 +321,24 @@ static int feed_append(pssbam_engine *e, const uint8_t *comp, const pssbam_bgzf_
     FeedAcc &s = e->feed[e->cur_feed];
     int rc;
     if (s.busy) {   // its previous super-batch must have been consumed before its buffers are overwritten
+        const double t0 = feed_now();
         HIP_TRY(hipEventSynchronize(s.consumed));
+        e->feed_t_wait_busy += feed_now() - t0;
         s.busy = false;
     }
+    const double t_alloc0 = feed_now();
     if (!s.d_comp) {
         s.comp_cap = (size_t)e->feed_comp_cap;
-        HIP_TRY(hipMalloc(&s.d_comp, s.comp_cap + 64));
+        if (!feed_take_reserved(e->device, s.comp_cap, &s.d_comp, &s.d_out, &s.out_cap)) HIP_TRY(hipMalloc(&s.d_comp, s.comp_cap + 64));
     }
     const uint64_t byte0 = blocks[b0].in_off & ~15ull, byte1 = blocks[b1 - 1].in_off + blocks[b1 - 1].in_len;
     const uint64_t out_bytes = blocks[b1 - 1].out_off + blocks[b1 - 1].isize - blocks[b0].out_off;
     if (s.out_cap < s.out_used + out_bytes + 8192) {
         if (s.out_used) return fail(PSSBAM_ESTATE, "output buffer of the super-batch cannot grow while it holds blocks");
-        const uint64_t need_out = std::max<uint64_t>(e->feed_out_target, out_bytes) + (2ull << 30) + 8192;
+        const uint64_t need_out = std::max<uint64_t>(e->feed_out_target, out_bytes) + FEED_OUT_SLACK;
         if ((rc = grow(&s.d_out, &s.out_cap, (size_t)need_out))) return rc;
     }
+    e->feed_t_alloc += feed_now() - t_alloc0;
     // blocks: in_off -> into d_comp, out_off -> into d_out; a new tally sub-batch where the record
     // bytes would pass 3.5 GiB or where bytes must be skipped in front of the first record
     const uint64_t comp_at = (s.comp_used + 15ull) & ~15ull;
@@ -317,7 +374,7 @@ extern "C" int pssbam_engine_submit_bgzf(pssbam_engine *e, const void *comp, uin
     if (!comp || !blocks) return fail(PSSBAM_EINVAL, "null buffer");
     if (e->cfg.kernel == PSSBAM_KERNEL_SIMPLE) return fail(PSSBAM_EINVAL, "device-indexed blocks need the tiled kernels");
     const uint64_t out_bytes = blocks[n_blocks - 1].out_off + blocks[n_blocks - 1].isize;
-    if (out_bytes > (2ull << 30)) return fail(PSSBAM_EINVAL, "chunk inflates to %llu bytes; keep chunks below 2 GiB", (unsigned long long)out_bytes);
+    if (out_bytes > (1ull << 30)) return fail(PSSBAM_EINVAL, "chunk inflates to %llu bytes; keep chunks at or below 1 GiB", (unsigned long long)out_bytes);
     if (blocks[0].out_off != 0) return fail(PSSBAM_EINVAL, "blocks[0].out_off must be 0");
     if (first_record_offset > blocks[0].isize) return fail(PSSBAM_EINVAL, "first_record_offset lies beyond the first block");
     if (comp_bytes > e->feed_comp_cap / 2) return fail(PSSBAM_EINVAL, "chunk of %llu compressed bytes is too large", (unsigned long long)comp_bytes);
@@ -347,6 +404,7 @@ extern "C" int pssbam_engine_submit_bgzf(pssbam_engine *e, const void *comp, uin
         const uint64_t comp0 = blocks[b0].in_off & ~15ull, out0 = blocks[b0].out_off;
         while (b1 < n_blocks && cur.blocks.size() + (b1 - b0) < block_target &&
                cur.out_used + (blocks[b1].out_off + blocks[b1].isize - out0) + 512 <= byte_target + (1ull << 30) &&
+               cur.out_used + (blocks[b1].out_off + blocks[b1].isize - out0) + 8192 <= std::max<uint64_t>(cur.out_cap, e->feed_out_target + FEED_OUT_SLACK) &&
                cur.comp_used + (blocks[b1].in_off + blocks[b1].in_len - comp0) + 64 <= e->feed_comp_cap)
             b1++;
         if (b1 == b0) {
@@ -406,6 +464,9 @@ extern "C" int pssbam_engine_feed_status(pssbam_engine *e, uint32_t *flags, doub
         e->event_pool.push_back(p.second);
     }
     e->inflate_events.clear();
+    if (getenv("PSSBAM_STATS"))
+        fprintf(stderr, "[pssbam] engine feed: buffer allocation %.3f, waiting for a busy super-batch %.3f, flush (block table + launches) %.3f s\n",
+                e->feed_t_alloc, e->feed_t_wait_busy, e->feed_t_flush);
     if (flags) *flags = f;
     if (inflate_ms) *inflate_ms = e->inflate_ms;
     if (inflated_bytes) *inflated_bytes = e->inflated_bytes;

@@ -13,8 +13,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <string>
 #include <memory>
+#include <mutex>
 #include <vector>
 
 #include "tally_kernels.h"
@@ -77,6 +79,9 @@ struct Slot {  // one in-flight host-submitted block
     uint64_t ticket = 0;      // the submit that last used the slot
 };
 
+// per super-batch: output of two rounds of the inflate kernel's 49 152 lanes (2 x 3.2 GB), and room for its compressed bytes
+static constexpr uint64_t FEED_OUT_TARGET = 6600ull << 20, FEED_COMP_CAP = 2ull << 30, FEED_OUT_SLACK = (1ull << 30) + (64ull << 20);
+
 struct FeedAcc {  // one super-batch of compressed blocks: assembled chunk by chunk, then inflated in ONE launch
     uint8_t *d_comp = nullptr;      // compressed bytes of the chunks, back to back (each 16-byte aligned)
     size_t comp_cap = 0;
@@ -138,7 +143,8 @@ struct pssbam_engine {
     // device-side inflate feed
     FeedAcc feed[2];
     int cur_feed = 0;
-    uint64_t feed_out_target = 12ull << 30, feed_comp_cap = 4ull << 30;   // per super-batch
+    uint64_t feed_out_target = FEED_OUT_TARGET, feed_comp_cap = FEED_COMP_CAP;   // per super-batch
+    double feed_t_alloc = 0, feed_t_wait_busy = 0, feed_t_flush = 0;   // host seconds inside the feed (PSSBAM_STATS)
     uint64_t feed_block_target = 0;   // blocks per super-batch: a whole number of rounds of the inflate kernel's lanes
     std::vector<std::pair<uint64_t, hipEvent_t>> feed_copies;             // (ticket, copy-complete event) of submits
     std::vector<hipEvent_t> feed_event_pool;

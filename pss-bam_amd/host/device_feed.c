@@ -129,7 +129,8 @@ int run_device_feed(pssbam_engine *const *eng, int n_gpus, const char *path, siz
     if (L.W < ((size_t)1 << 20)) L.W = (size_t)1 << 20;
     L.W &= ~(size_t)4095;
     L.n_chunks = (long)((L.file_size + L.W - 1) / L.W);
-    const size_t out_cap = env_size("PSSBAM_FEED_BATCH_BYTES", (size_t)1 << 30); /* inflated bytes per submit */
+    size_t out_cap = env_size("PSSBAM_FEED_BATCH_BYTES", (size_t)768 << 20); /* inflated bytes per submit */
+    if (out_cap > ((size_t)1 << 30)) out_cap = (size_t)1 << 30;
     const int max_inflight = n_gpus * run < 2 ? 2 : n_gpus * run;
     L.n_st = max_inflight + 4 > MAX_STAGE ? MAX_STAGE : max_inflight + 4;
     if ((long)L.n_st > L.n_chunks + 1) L.n_st = (int)L.n_chunks + 1;

@@ -36,6 +36,8 @@ static void *warmup_main(void *arg)
     (void)arg;
     const int n = env_gpu_count(); /* the first HIP call: runtime start-up happens here */
     for (int g = 0; g < n; g++) (void)pssbam_warmup(g); /* failures surface in pssbam_engine_create */
+    if (early_rd && early_light && !getenv("PSSBAM_OVERSUBSCRIBE"))
+        for (int g = 0; g < n; g++) (void)pssbam_feed_reserve(g); /* the device feed's buffers, while the FASTA loads (best effort) */
     if (early_rd && !early_light && !getenv("PSSBAM_NO_PIN")) {
         void *base;
         size_t bytes;
