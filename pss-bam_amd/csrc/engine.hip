@@ -355,10 +355,22 @@ extern "C" int pssbam_engine_set_genome_arrays(pssbam_engine *e, size_t n, const
     // padding = raw NUL, like the terminator the reference finds at index len (fragkon.c odd-k
     // windows); the encode pass below turns it into the stored form of NUL ("not a base")
     HIP_TRY(hipMemsetAsync(e->d_genome, 0, total, e->stream));
+    // Host contigs: large ones are page-locked for the copy (cheap when the loader put them on
+    // transparent huge pages: 2 MiB per pin instead of 4 KiB), which turns a staged pageable copy into
+    // one DMA at link speed; if the lock is refused the plain copy below does the job.
+    std::vector<const void *> locked;
+    const bool try_lock = !seqs_on_device && !getenv("PSSBAM_NO_PIN");
     for (size_t k = 0; k < n; k++) {
         if (!len[k]) continue;
-        HIP_TRY(hipMemcpyAsync(e->d_genome + start[k], seqs[order[k]], len[k],
+        const void *src = seqs[order[k]];
+        if (try_lock && len[k] >= (32u << 20) && hipHostRegister((void *)src, len[k], hipHostRegisterDefault) == hipSuccess) locked.push_back(src);
+        else (void)hipGetLastError();
+        HIP_TRY(hipMemcpyAsync(e->d_genome + start[k], src, len[k],
                                seqs_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, e->stream));
+    }
+    if (!locked.empty()) {
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        for (const void *p : locked) (void)hipHostUnregister((void *)p);
     }
     // raw bytes (and NUL padding) are in place: one pass folds case and applies enc_byte to all
     hipLaunchKernelGGL(encode_genome_kernel, dim3(4096), dim3(256), 0, e->stream, e->d_genome, total / 16);

@@ -35,6 +35,28 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <sys/mman.h>
+
+/* A contig's bases.  Big ones ask for transparent huge pages (the box runs THP in "madvise" mode):
+ * a 3.1 Gb genome is 800 000 first-touch faults in 4 KiB pages and 1 500 in 2 MiB pages -- faster
+ * to fill by the parser threads, to pin for the upload, and to give back at exit.  free()-able, as
+ * destroy_seq expects (fasta-genome-io.c:241-248). */
+static char *contig_alloc(size_t bytes)
+{
+    const size_t huge = (size_t)2 << 20;
+    if (bytes >= 4 * huge) {
+        const size_t rounded = (bytes + huge - 1) & ~(huge - 1);
+        void *p = NULL;
+        if (posix_memalign(&p, huge, rounded) == 0) {
+#ifdef MADV_HUGEPAGE
+            (void)madvise(p, rounded, MADV_HUGEPAGE);
+#endif
+            return (char *)p;
+        }
+    }
+    return (char *)malloc(bytes);
+}
+
 /* byte classes for the block parser */
 enum { C_BASE = 0, C_SPACE = 1, C_GT = 2 };
 static unsigned char g_class[256];
@@ -423,7 +445,7 @@ static int load_parallel(const char fn[], Genome **out)
             for (size_t c = 0; c < genome->n_seqs; c++) {
                 Seq *sq = genome->seqs[c];
                 if (sq->len > (size_t)MAX_SEQ_LEN) { applicable = 0; break; } /* truncation corner: serial parser */
-                sq->seq = (char *)malloc(sq->len + 1);
+                sq->seq = contig_alloc(sq->len + 1);
                 if (!sq->seq) { applicable = 0; break; }
                 sq->seq[sq->len] = '\0';
             }

@@ -23,6 +23,7 @@
 
 int main(int argc, char *argv[])
 {
+    const double t_main = frontend_now_s();
     int region_len = 15, min_mq = 0, merged_only = 0, option;
     unsigned long min_read_len = 0, max_read_len = 250000000;
     const char *up_ctx = "ACGT", *down_ctx = "ACGT";
@@ -127,6 +128,7 @@ int main(int argc, char *argv[])
                 res.stats[PSSBAM_ST_SLOW_PATH] * 100 > res.stats[PSSBAM_ST_RECORDS]
                     ? "  (more than 1 % of the records were longer than the staged prefix and took the one-lane path: slower, same tables)" : "");
         fprintf(stderr, "[pssbam] gpus=%d inflate_s=%.3f total_s=%.3f\n", res.n_gpus, res.inflate_s, res.total_s);
+        fprintf(stderr, "[pssbam] main() to reports written: %.3f s\n", frontend_now_s() - t_main);
     }
     if (frontend_fast_exit) { /* nothing left to do but to hand the memory back: let the OS */
         fprintf(stderr, "Done.\n");

@@ -64,12 +64,15 @@ for st in settings:
     thr = re.search(r"device feed, this thread: (.*)\n", best[1])
     ph = re.search(r"phases: (.*)\n", best[1])
     ef = re.search(r"engine feed: (.*)\n", best[1])
+    mn = re.search(r"main\(\) to reports written: ([\d.]+) s", best[1])
+    fl = re.search(r"fasta load ([\d.]+) s", best[1])
     tally = re.search(r"total_s=([\d.]+)", best[1])
     print(json.dumps({"setting": st or "(default)", "wall_s": round(best[0], 3), "reads_per_s": round(args.reads / best[0]),
                       "tally_phase_s": float(tally.group(1)) if tally else None, "same_tables": counts == ref_counts,
                       "device_feed": feed.group(1) if feed else None, "feed_thread": thr.group(1) if thr else None,
                       "phases": ph.group(1) if ph else None,
-                      "engine_feed": ef.group(1) if ef else None}), flush=True)
+                      "engine_feed": ef.group(1) if ef else None, "main_to_reports_s": float(mn.group(1)) if mn else None,
+                      "fasta_load_s": float(fl.group(1)) if fl else None}), flush=True)
 for p in tmp.iterdir():
     p.unlink()
 tmp.rmdir()
