@@ -88,7 +88,7 @@ extern "C" int pssbam_bgzf_inflate_device(void *hip_stream, const void *d_comp, 
     }
     const uint32_t groups = (n_blocks + pssbam::INF_WAVE - 1) / pssbam::INF_WAVE;
     const char *gm = getenv("PSSBAM_INFLATE_WAVES_PER_CU");
-    const uint32_t per_cu = gm && atoi(gm) > 0 ? (uint32_t)atoi(gm) : 3u;
+    const uint32_t per_cu = gm && atoi(gm) > 0 ? (uint32_t)atoi(gm) : (uint32_t)pssbam::INF_WAVES_PER_CU;
     const uint32_t grid = std::min<uint32_t>(groups, (uint32_t)n_cu * per_cu);
     hipLaunchKernelGGL(pssbam::bgzf_inflate_kernel, dim3(grid), dim3(pssbam::INF_WAVE), pssbam::INF_LDS_BYTES, st, (const uint8_t *)d_comp, comp_bytes,
                        (pssbam::BgzfBlock *)d_blocks, n_blocks, (uint8_t *)d_out);
@@ -383,7 +383,7 @@ extern "C" int pssbam_engine_submit_bgzf(pssbam_engine *e, const void *comp, uin
         if (getenv("PSSBAM_FEED_SUPER_BYTES")) e->feed_out_target = std::max<uint64_t>(1ull << 20, strtoull(getenv("PSSBAM_FEED_SUPER_BYTES"), nullptr, 10));
         // the inflate kernel keeps 3 waves x 64 lanes per CU busy, a block per lane, and blocks take about the
         // same time: a super-batch of a whole number of "rounds" of blocks wastes no partial round
-        const uint64_t lanes = (uint64_t)e->n_cu * 3ull * 64ull;
+        const uint64_t lanes = (uint64_t)e->n_cu * (uint64_t)pssbam::INF_WAVES_PER_CU * 64ull;
         const uint64_t rounds = std::max<uint64_t>(1, e->feed_out_target / (lanes * 65280ull));
         e->feed_block_target = getenv("PSSBAM_FEED_SUPER_BYTES") && e->feed_out_target < lanes * 65280ull ? 0xFFFFFFFFull : rounds * lanes;
         HIP_TRY(hipMalloc(&e->d_feed_flags, sizeof(uint32_t)));
@@ -397,7 +397,7 @@ extern "C" int pssbam_engine_submit_bgzf(pssbam_engine *e, const void *comp, uin
         const bool first = e->inflated_bytes == 0 && !e->feed[e->cur_feed ^ 1].busy;
         const uint64_t byte_target = first ? e->feed_out_target / 3 : e->feed_out_target;
         const uint64_t block_target = e->feed_block_target == 0xFFFFFFFFull ? 0xFFFFFFFFull
-                                      : first ? std::max<uint64_t>(e->feed_block_target / 3 / ((uint64_t)e->n_cu * 192ull), 1) * ((uint64_t)e->n_cu * 192ull)
+                                      : first ? (uint64_t)e->n_cu * 64ull * pssbam::INF_WAVES_PER_CU / 2ull   // half a round: the device starts early
                                               : e->feed_block_target;
         // how many of the remaining blocks still fit
         uint32_t b1 = b0;

@@ -79,8 +79,8 @@ struct Slot {  // one in-flight host-submitted block
     uint64_t ticket = 0;      // the submit that last used the slot
 };
 
-// per super-batch: output of two rounds of the inflate kernel's 49 152 lanes (2 x 3.2 GB), and room for its compressed bytes
-static constexpr uint64_t FEED_OUT_TARGET = 6600ull << 20, FEED_COMP_CAP = 2ull << 30, FEED_OUT_SLACK = (1ull << 30) + (64ull << 20);
+// per super-batch: output of two rounds of the inflate kernel's 81 920 lanes (2 x 5.35 GB), and room for its compressed bytes
+static constexpr uint64_t FEED_OUT_TARGET = 10800ull << 20, FEED_COMP_CAP = 2ull << 30, FEED_OUT_SLACK = (1ull << 30) + (64ull << 20);
 
 struct FeedAcc {  // one super-batch of compressed blocks: assembled chunk by chunk, then inflated in ONE launch
     uint8_t *d_comp = nullptr;      // compressed bytes of the chunks, back to back (each 16-byte aligned)

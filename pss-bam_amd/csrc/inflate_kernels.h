@@ -27,7 +27,7 @@
 // CRCs combined by multiplication with x^(8*bytes behind the chunk) mod P).
 //
 // Bound: latency (LDS + L2 round trips on a serial chain), hidden by block-level parallelism:
-// 3 waves x 64 lanes x 256 CUs = 49 152 streams in flight.  Integer/bit work; no MFMA.
+// 5 waves x 64 lanes x 256 CUs = 81 920 streams in flight.  Integer/bit work; no MFMA.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -48,18 +48,39 @@ enum : uint32_t { INF_OK = 0, INF_BAD_BLOCK = 1, INF_BAD_CODES = 2, INF_BAD_SYMB
                   INF_SHORT = 6, INF_TRUNCATED = 7, INF_BAD_CRC = 8 };
 
 constexpr int INF_WAVE = 64;
-// per-lane LDS, in u16 entries (lane-interleaved)
-constexpr int L_DELTA = 0;        // [16]  litlen: sorted-symbol index base minus first code, per code length
-constexpr int L_OFFS = 16;        // [16]  scratch while a table is built: next free slot per code length
-constexpr int L_SYM = 32;         // [288] litlen symbols sorted by (code length, symbol)
-constexpr int D_DELTA = 320;      // [16]  distance
-constexpr int D_SYM = 336;        // [32]  distance symbols (also hosts the 19-symbol code-length code)
-constexpr int INF_LDS_U16 = 368;  // 736 B per lane
-constexpr uint32_t INF_LDS_BYTES = INF_LDS_U16 * INF_WAVE * 2;
+// per-lane LDS, lane-interleaved, in three arrays of different element width:
+//   u16[48]  : L_DELTA[16] litlen index base minus first code per code length; L_OFFS[16] scratch while a
+//              table is built (next free slot per length); D_DELTA[16] the same for the distance code
+//   u8[320]  : L_SYM[288] low 8 bits of the litlen symbols sorted by (code length, symbol);
+//              D_SYM[32] distance symbols (also hosts the 19-symbol code-length code)
+//   u32[9]   : bit 8 of the 288 litlen symbols
+// = 452 B per lane, 28.3 KiB per wave: FIVE waves per CU (the 16-bit symbol table of the first version
+// allowed three).
+constexpr int L_DELTA = 0, L_OFFS = 16, D_DELTA = 32, INF_N16 = 48;
+constexpr int L_SYM = 0, D_SYM = 288, INF_N8 = 320;
+constexpr int INF_N32 = 9;
+constexpr uint32_t INF_LDS_BYTES = (INF_N16 * 2 + INF_N8 + INF_N32 * 4) * INF_WAVE;
+constexpr int INF_WAVES_PER_CU = 5;
 
-struct LaneLds {  // this lane's view of the interleaved table
-    uint16_t *base;
-    __device__ __forceinline__ uint16_t &at(int i) const { return base[i * INF_WAVE]; }
+struct LaneLds {  // this lane's view of the three interleaved arrays
+    uint16_t *b16;
+    uint8_t *b8;
+    uint32_t *b32;
+    __device__ __forceinline__ uint16_t &at(int i) const { return b16[i * INF_WAVE]; }
+    __device__ __forceinline__ uint8_t &sym8(int i) const { return b8[i * INF_WAVE]; }
+    __device__ __forceinline__ void clear_hi() const {
+#pragma unroll
+        for (int k = 0; k < INF_N32; k++) b32[k * INF_WAVE] = 0u;
+    }
+    // litlen symbol (9 bits) at sorted position i
+    __device__ __forceinline__ void put_litlen(uint32_t i, uint32_t sym) const {
+        b8[(L_SYM + (int)i) * INF_WAVE] = (uint8_t)sym;
+        if (sym >> 8) b32[(i >> 5) * INF_WAVE] |= 1u << (i & 31u);
+    }
+    __device__ __forceinline__ uint32_t get_litlen(uint32_t i) const {
+        const uint32_t lo = b8[(L_SYM + (int)i) * INF_WAVE], hi = b32[(i >> 5) * INF_WAVE];
+        return lo | (((hi >> (i & 31u)) & 1u) << 8);
+    }
 };
 
 struct BitReader {
@@ -119,8 +140,9 @@ __device__ __forceinline__ bool huff_finish(const LaneLds &t, int cnt_at, int de
     return ok;
 }
 
-// symbol for the next code of the stream; < 0: the bits are no code of this table
-template <int MAXL>
+// symbol for the next code of the stream; < 0: the bits are no code of this table.
+// WIDE: the literal/length table (9-bit symbols); else a u8 table at sym_at (distance / code-length code)
+template <int MAXL, bool WIDE>
 __device__ __forceinline__ int huff_decode(BitReader &br, const LaneLds &t, int delta_at, int sym_at, int n_sym,
                                            const uint32_t (&upper)[15]) {
     const uint32_t c15 = br.peek15();
@@ -131,7 +153,7 @@ __device__ __forceinline__ int huff_decode(BitReader &br, const LaneLds &t, int 
     const uint32_t idx = ((c15 >> (15u - L)) + t.at(delta_at + (int)L)) & 0xFFFFu;
     if (idx >= (uint32_t)n_sym) return -1;
     br.drop(L);
-    return (int)t.at(sym_at + (int)idx);
+    return WIDE ? (int)t.get_litlen(idx) : (int)t.sym8(sym_at + (int)idx);
 }
 
 __device__ __forceinline__ uint64_t load_u64(const uint8_t *p) {
@@ -198,17 +220,18 @@ __device__ uint32_t inflate_block(const uint8_t *comp, uint64_t comp_bytes, cons
                 for (int L = 0; L < 16; L++) { t.at(L_OFFS + L) = 0; t.at(D_DELTA + L) = 0; }
                 t.at(L_OFFS + 7) = 24; t.at(L_OFFS + 8) = 152; t.at(L_OFFS + 9) = 112;
                 (void)huff_finish<15>(t, L_OFFS, L_DELTA, lu);
+                t.clear_hi();
                 for (int s = 0; s < 288; s++) {
                     const int L = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8;
                     const uint32_t o = t.at(L_OFFS + L);
-                    t.at(L_SYM + (int)o) = (uint16_t)s;
+                    t.put_litlen(o, (uint32_t)s);
                     t.at(L_OFFS + L) = (uint16_t)(o + 1u);
                 }
 #pragma unroll
                 for (int L = 0; L < 16; L++) t.at(L_OFFS + L) = 0;
                 t.at(L_OFFS + 5) = 30;
                 (void)huff_finish<15>(t, L_OFFS, D_DELTA, du);
-                for (int s = 0; s < 30; s++) t.at(D_SYM + s) = (uint16_t)s;
+                for (int s = 0; s < 30; s++) t.sym8(D_SYM + s) = (uint8_t)s;
             } else {
                 // dynamic code: HLIT, HDIST, HCLEN, the code-length code, then the two codes' lengths
                 br.refill();
@@ -233,7 +256,7 @@ __device__ uint32_t inflate_block(const uint8_t *comp, uint64_t comp_bytes, cons
                         const uint32_t l = (uint32_t)(cl_packed >> (3u * s)) & 7u;
                         if (l) {
                             const uint32_t o = t.at(L_OFFS + (int)l);
-                            t.at(D_SYM + (int)o) = (uint16_t)s;
+                            t.sym8(D_SYM + (int)o) = (uint8_t)s;
                             t.at(L_OFFS + (int)l) = (uint16_t)(o + 1u);
                         }
                     }
@@ -252,6 +275,7 @@ __device__ uint32_t inflate_block(const uint8_t *comp, uint64_t comp_bytes, cons
 #pragma unroll
                         for (int L = 0; L < 16; L++) t.at(L_OFFS + L) = lcount[L];
                         if (!huff_finish<15>(t, L_OFFS, L_DELTA, lu)) return INF_BAD_CODES;
+                        t.clear_hi();
                     } else {
 #pragma unroll
                         for (int L = 0; L < 16; L++) { lcount[L] = 0; dcount[L] = 0; }
@@ -262,7 +286,7 @@ __device__ uint32_t inflate_block(const uint8_t *comp, uint64_t comp_bytes, cons
                     uint64_t dl_lo = 0, dl_hi = 0;
                     while (idx < nlen + ndist) {
                         br.refill();
-                        const int sym = huff_decode<7>(br, t, D_DELTA, D_SYM, (int)n_cl_sym, cu);
+                        const int sym = huff_decode<7, false>(br, t, D_DELTA, D_SYM, (int)n_cl_sym, cu);
                         if (sym < 0) return INF_BAD_CODES;
                         uint32_t len = (uint32_t)sym, rep = 1u;
                         if (sym >= 16) {
@@ -280,7 +304,7 @@ __device__ uint32_t inflate_block(const uint8_t *comp, uint64_t comp_bytes, cons
                                     for (int L = 1; L < 16; L++) lcount[L] = (uint16_t)(lcount[L] + ((uint32_t)L == len ? 1u : 0u));
                                 } else {
                                     const uint32_t o = t.at(L_OFFS + (int)len);
-                                    t.at(L_SYM + (int)o) = (uint16_t)idx;
+                                    t.put_litlen(o, idx);
                                     t.at(L_OFFS + (int)len) = (uint16_t)(o + 1u);
                                 }
                             } else {
@@ -305,7 +329,7 @@ __device__ uint32_t inflate_block(const uint8_t *comp, uint64_t comp_bytes, cons
                             const uint32_t l = (uint32_t)((d < 16u ? dl_lo >> (4u * d) : dl_hi >> (4u * (d - 16u))) & 15ull);
                             if (l) {
                                 const uint32_t o = t.at(L_OFFS + (int)l);
-                                t.at(D_SYM + (int)o) = (uint16_t)d;
+                                t.sym8(D_SYM + (int)o) = (uint8_t)d;
                                 t.at(L_OFFS + (int)l) = (uint16_t)(o + 1u);
                             }
                         }
@@ -315,7 +339,7 @@ __device__ uint32_t inflate_block(const uint8_t *comp, uint64_t comp_bytes, cons
             // ---- the compressed data of this deflate block ------------------------------------
             for (;;) {
                 br.refill();
-                const int sym = huff_decode<15>(br, t, L_DELTA, L_SYM, 288, lu);
+                const int sym = huff_decode<15, true>(br, t, L_DELTA, L_SYM, 288, lu);
                 if (sym < 0) return INF_BAD_SYMBOL;
                 if (sym < 256) {
                     if (pos >= isize) return INF_OVERRUN;
@@ -336,7 +360,7 @@ __device__ uint32_t inflate_block(const uint8_t *comp, uint64_t comp_bytes, cons
                     }
                 }
                 br.refill();
-                const int ds = huff_decode<15>(br, t, D_DELTA, D_SYM, 30, du);
+                const int ds = huff_decode<15, false>(br, t, D_DELTA, D_SYM, 30, du);
                 if (ds < 0) return INF_BAD_DISTANCE;
                 uint32_t dist;
                 {
@@ -410,9 +434,10 @@ __device__ uint32_t inflate_block(const uint8_t *comp, uint64_t comp_bytes, cons
 // grid of single-wave workgroups, each wave takes 64 consecutive blocks at a time
 __global__ void __launch_bounds__(INF_WAVE) bgzf_inflate_kernel(const uint8_t *comp, uint64_t comp_bytes, BgzfBlock *blocks,
                                                                 uint32_t n_blocks, uint8_t *out) {
-    extern __shared__ __attribute__((aligned(16))) uint16_t inf_lds[];
+    extern __shared__ __attribute__((aligned(16))) uint8_t inf_lds[];
     const uint32_t lane = threadIdx.x;
-    const LaneLds t{inf_lds + lane};
+    const LaneLds t{(uint16_t *)inf_lds + lane, inf_lds + INF_N16 * 2 * INF_WAVE + lane,
+                    (uint32_t *)(inf_lds + (INF_N16 * 2 + INF_N8) * INF_WAVE) + lane};
     for (uint32_t g = blockIdx.x; g * INF_WAVE < n_blocks; g += gridDim.x) {
         const uint32_t i = g * INF_WAVE + lane;
         if (i < n_blocks) {
