@@ -247,6 +247,10 @@ int pssbam_engine_wait_bgzf_copied(pssbam_engine *e, uint64_t ticket);
 #define PSSBAM_FEED_RAGGED 2u      /* records cross BGZF blocks: use the host reader for this file     */
 #define PSSBAM_FEED_BAD_RECORD 4u  /* an alignment record with block_size < 32                        */
 int pssbam_engine_feed_status(pssbam_engine *e, uint32_t *flags, double *inflate_ms, uint64_t *inflated_bytes);
+/* Optional, before pssbam_engine_submit_bgzf / _submit_device: a few whole alignment records in host
+ * memory (e.g. the first ones of the file) from which the tiled kernels' staged record prefix is
+ * sized -- otherwise the engine reads the first block back from the device to look at its records. */
+int pssbam_engine_hint_records(pssbam_engine *e, const void *records, uint64_t nbytes);
 /* Optional: allocates the feed's device buffers (~17 GB) for `device` ahead of time, e.g. from a helper
  * thread while the FASTA loads; the first engine on that device that feeds compressed blocks takes them. */
 int pssbam_feed_reserve(int device);

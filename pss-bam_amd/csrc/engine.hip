@@ -714,6 +714,17 @@ static int launch_tally(pssbam_engine *e, const uint8_t *d_recs, uint64_t nbytes
     return PSSBAM_OK;
 }
 
+// A caller that will only hand over device-resident or compressed blocks can show the engine a few
+// host-side records first: the tiled kernels' staged prefix is then sized from them instead of from a
+// read-back of the first block (which has to wait for that block to be inflated).
+extern "C" int pssbam_engine_hint_records(pssbam_engine *e, const void *records, uint64_t nbytes) {
+    if (!e || (!records && nbytes)) return fail(PSSBAM_EINVAL, "null argument");
+    if (nbytes < 36) return PSSBAM_OK;
+    e->dev_pieces = pieces_for(sample_prefix_need((const uint8_t *)records, nbytes, e->has_rg, 1 << 16));
+    e->dev_pieces_avg = 40;
+    return PSSBAM_OK;
+}
+
 static int check_ready(pssbam_engine *e) {
     if (!e) return fail(PSSBAM_EINVAL, "null engine");
     if (!e->d_genome) return fail(PSSBAM_ESTATE, "set_genome has not been called");

@@ -47,6 +47,12 @@ typedef struct {
     long free_for;         /* chunk index that may load into this slot next */
     long loaded;           /* chunk index whose bytes are in buf, or -1 */
     int io_error;
+    /* the loader's own walk of the window's block headers, from the first offset at which a chain of
+     * BGZF headers starts (offset 0 in chunk 0): used by the submitting thread iff that offset is where
+     * the previous chunk's chain really ends -- the walk then costs the submitting thread nothing */
+    pssbam_bgzf_block *pre;
+    size_t pre_start;      /* offset in buf the walk started from */
+    int64_t pre_n;         /* blocks found (-1: none) */
 } stage_t;
 
 typedef struct {
@@ -83,6 +89,28 @@ static void *loader_main(void *arg)
             got += (size_t)n;
         }
         memset(s->buf + got, 0, 16); /* the device decoder may read one dword past the payload */
+        s->pre_n = -1;
+        if (!bad && s->pre) {
+            size_t st = 0;
+            int found = k == 0;
+            for (; !found && st + 64 < got && st < ((size_t)66 << 10); st++) { /* a block is at most 64 KiB: one starts in here */
+                const uint8_t *h = s->buf + st;
+                if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || h[3] != 4 || h[12] != 'B' || h[13] != 'C' || h[14] != 2 || h[15] != 0) continue;
+                size_t o = st; /* three headers in a row make a false start improbable; the submitting thread checks anyway */
+                int hops = 0;
+                while (hops < 3 && o + 18 <= got && s->buf[o] == 0x1f && s->buf[o + 1] == 0x8b && s->buf[o + 12] == 'B' && s->buf[o + 13] == 'C') {
+                    o += (size_t)(s->buf[o + 16] | (s->buf[o + 17] << 8)) + 1;
+                    hops++;
+                }
+                if (hops == 3 || o >= got) found = 1;
+                if (found) break;
+            }
+            if (found) {
+                uint64_t consumed = 0;
+                s->pre_start = st;
+                s->pre_n = pssbam_bgzf_scan(s->buf + st, got - st, s->pre, BLOCKS_PER_SCAN, &consumed, NULL);
+            }
+        }
         pthread_mutex_lock(&L->mu);
         s->len = got;
         s->io_error = bad;
@@ -132,7 +160,7 @@ int run_device_feed(pssbam_engine *const *eng, int n_gpus, const char *path, siz
     size_t out_cap = env_size("PSSBAM_FEED_BATCH_BYTES", (size_t)768 << 20); /* inflated bytes per submit */
     if (out_cap > ((size_t)1 << 30)) out_cap = (size_t)1 << 30;
     const int max_inflight = n_gpus * run < 2 ? 2 : n_gpus * run;
-    L.n_st = max_inflight + 4 > MAX_STAGE ? MAX_STAGE : max_inflight + 4;
+    L.n_st = max_inflight + 8 > MAX_STAGE ? MAX_STAGE : max_inflight + 8;   /* windows being read ahead + in flight */
     if ((long)L.n_st > L.n_chunks + 1) L.n_st = (int)L.n_chunks + 1;
     const size_t slot_bytes = (L.W + OVER + 4096 + 4095) & ~(size_t)4095;
     pthread_mutex_init(&L.mu, NULL);
@@ -145,11 +173,12 @@ int run_device_feed(pssbam_engine *const *eng, int n_gpus, const char *path, siz
         L.st[i].buf = stage_base + (size_t)i * slot_bytes;
         L.st[i].free_for = i;
         L.st[i].loaded = -1;
+        L.st[i].pre = (pssbam_bgzf_block *)malloc(sizeof(pssbam_bgzf_block) * BLOCKS_PER_SCAN); /* NULL: no pre-scan, that is all */
     }
     if (!getenv("PSSBAM_NO_PIN")) registered = pssbam_host_register(stage_base, slot_bytes * (size_t)L.n_st) == 0;
     {
         long cpus = sysconf(_SC_NPROCESSORS_ONLN);
-        int want = (int)env_size("PSSBAM_LOADER_THREADS", 6);
+        int want = (int)env_size("PSSBAM_LOADER_THREADS", 8);
         if (want > 16) want = 16;
         if (cpus > 0 && want > cpus) want = (int)cpus;
         if ((long)want > L.n_chunks) want = (int)L.n_chunks;
@@ -183,6 +212,7 @@ int run_device_feed(pssbam_engine *const *eng, int n_gpus, const char *path, siz
     } while (0)
 
     double t_wait_load = 0, t_wait_copy = 0, t_scan = 0, t_submit = 0;
+    long n_prescanned = 0;
     size_t pos = 0;                /* file offset of the next BGZF block */
     size_t skip = header_bytes;    /* inflated bytes still to skip in front of the first record */
     uint64_t n_submits = 0;
@@ -200,7 +230,15 @@ int run_device_feed(pssbam_engine *const *eng, int n_gpus, const char *path, siz
             if (pos < win0) { fprintf(stderr, "Error: %s: BGZF block chain lost\n", path); goto done; }
             uint64_t consumed = 0, inflated = 0;
             const double ts = mono_s();
-            const int64_t n = pssbam_bgzf_scan(s->buf + (pos - win0), s->len - (pos - win0), blocks, BLOCKS_PER_SCAN, &consumed, &inflated);
+            int64_t n;
+            const pssbam_bgzf_block *bl = blocks;
+            if (s->pre && s->pre_n > 0 && s->pre_start == pos - win0) { /* the loader walked exactly this chain already */
+                n = s->pre_n;
+                bl = s->pre;
+                s->pre_n = -1; /* (a second pass over this window, after 65536 blocks, walks for itself) */
+                n_prescanned++;
+            } else
+                n = pssbam_bgzf_scan(s->buf + (pos - win0), s->len - (pos - win0), blocks, BLOCKS_PER_SCAN, &consumed, &inflated);
             t_scan += mono_s() - ts;
             if (n < 0) { fprintf(stderr, "Error: %s: %s\n", path, pssbam_last_error()); goto done; }
             if (n == 0) {
@@ -212,26 +250,26 @@ int run_device_feed(pssbam_engine *const *eng, int n_gpus, const char *path, siz
             int64_t keep = 0;
             size_t start = pos;
             while (keep < n && start < win_end) {
-                start = pos + (size_t)(blocks[keep].in_off + blocks[keep].in_len + 8);
+                start = pos + (size_t)(bl[keep].in_off + bl[keep].in_len + 8);
                 keep++;
             }
             const size_t chunk_rel = pos - win0;
             pos = start;
             /* cut into submits that inflate to <= out_cap; all-header blocks of the file's start are skipped */
             int64_t i = 0;
-            while (i < keep && skip > 0 && skip >= blocks[i].isize) { skip -= blocks[i].isize; i++; }
+            while (i < keep && skip > 0 && skip >= bl[i].isize) { skip -= bl[i].isize; i++; }
             while (i < keep) {
                 int64_t j = i;
-                const uint64_t base_out = blocks[i].out_off;
-                while (j < keep && blocks[j].out_off + blocks[j].isize - base_out <= out_cap) j++;
+                const uint64_t base_out = bl[i].out_off;
+                while (j < keep && bl[j].out_off + bl[j].isize - base_out <= out_cap) j++;
                 if (j == i) j = i + 1;
-                const uint64_t base_in = blocks[i].in_off & ~(uint64_t)3;
+                const uint64_t base_in = bl[i].in_off & ~(uint64_t)3;
                 for (int64_t b = i; b < j; b++) {
-                    grp[b - i] = blocks[b];
+                    grp[b - i] = bl[b];
                     grp[b - i].in_off -= base_in;
                     grp[b - i].out_off -= base_out;
                 }
-                const uint64_t end_in = blocks[j - 1].in_off + blocks[j - 1].in_len;
+                const uint64_t end_in = bl[j - 1].in_off + bl[j - 1].in_len;
                 const int g = (int)((n_submits / (uint64_t)run) % (uint64_t)n_gpus);
                 uint64_t ticket = 0;
                 const double tsub = mono_s();
@@ -284,8 +322,9 @@ int run_device_feed(pssbam_engine *const *eng, int n_gpus, const char *path, siz
                 fs->inflate_ms > 0 ? fs->inflated_bytes * 1e-6 / fs->inflate_ms : 0.0, n_th, L.n_st, L.W >> 20,
                 fs->fallback ? "; records cross BGZF blocks -> host reader" : "");
     if (verbose)
-        fprintf(stderr, "[pssbam] device feed, this thread: waiting for loaders %.3f, block-header walk %.3f, submit (incl. waiting for a "
-                        "free super-batch) %.3f, waiting for copies %.3f s\n", t_wait_load, t_scan, t_submit, t_wait_copy);
+        fprintf(stderr, "[pssbam] device feed, this thread: waiting for loaders %.3f, block-header walk %.3f (%ld of %ld windows walked by "
+                        "their loader), submit (incl. waiting for a free super-batch) %.3f, waiting for copies %.3f s\n", t_wait_load, t_scan,
+                n_prescanned, L.n_chunks, t_submit, t_wait_copy);
     rc = 0;
 done:
     pthread_mutex_lock(&L.mu);
@@ -295,6 +334,7 @@ done:
     for (int t = 0; t < n_th; t++) pthread_join(th[t], NULL);
     if (rc) for (int g = 0; g < n_gpus; g++) (void)pssbam_engine_sync(eng[g]); /* nothing may still read the staging slots */
     if (registered) pssbam_host_unregister(stage_base);
+    for (int i = 0; i < L.n_st; i++) free(L.st[i].pre);
     free(stage_base);
     free(blocks);
     free(grp);

@@ -194,6 +194,16 @@ int run_tally(const pssbam_config *cfg, Genome *genome, const char *aln_path, in
                 goto done;
             }
         refs_sent = h->n_ref;
+        { /* the light reader has inflated the file's first records on the host: let the engines size their
+           * staged record prefix from them (no read-back from the device later) */
+            const uint8_t *r0;
+            const uint32_t *o0;
+            size_t nb0;
+            int slot0 = -1;
+            if (bam_reader_next_hold(rd, &r0, &o0, &nb0, &slot0) > 0)
+                for (int g = 0; g < n_gpus; g++) (void)pssbam_engine_hint_records(eng[g], r0, nb0);
+            if (slot0 >= 0) bam_reader_release(rd, slot0);
+        }
         if (run_device_feed(eng, n_gpus, aln_path, bam_reader_header_bytes(rd), feed_run(n_gpus), verbose, &dfs)) goto done;
         if (dfs.fallback) {
             if (verbose) fprintf(stderr, "[pssbam] device feed not usable for this file: falling back to the host reader\n");
