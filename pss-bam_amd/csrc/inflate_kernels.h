@@ -61,24 +61,31 @@ constexpr int L_SYM = 0, D_SYM = 288, INF_N8 = 320;
 constexpr int INF_N32 = 9;
 constexpr uint32_t INF_LDS_BYTES = (INF_N16 * 2 + INF_N8 + INF_N32 * 4) * INF_WAVE;
 constexpr int INF_WAVES_PER_CU = 5;
+#ifndef INF_LIT_RUN
+#define INF_LIT_RUN 12u   // literals a lane may emit before the wave turns to the pending matches
+#endif
 
 struct LaneLds {  // this lane's view of the three interleaved arrays
-    uint16_t *b16;
-    uint8_t *b8;
-    uint32_t *b32;
-    __device__ __forceinline__ uint16_t &at(int i) const { return b16[i * INF_WAVE]; }
-    __device__ __forceinline__ uint8_t &sym8(int i) const { return b8[i * INF_WAVE]; }
+    // Interleaving is by DWORD: entry i of lane l sits in dword (i / per_dword) * 64 + l, so whatever
+    // entries the 64 lanes ask for, lane l always reads bank l % 32 -- no bank conflicts beyond the
+    // two-lanes-per-bank of a 64-wide wave (element-wise interleaving had the lanes of a wave collide
+    // 4-ways on the byte table: 45 % of the LDS cycles were conflict cycles).
+    uint8_t *b16;   // base of the u16 array + 4 * lane
+    uint8_t *b8;    // base of the u8 array + 4 * lane
+    uint32_t *b32;  // base of the u32 array + lane
+    __device__ __forceinline__ uint16_t &at(int i) const { return *(uint16_t *)(b16 + (i >> 1) * (INF_WAVE * 4) + (i & 1) * 2); }
+    __device__ __forceinline__ uint8_t &sym8(int i) const { return b8[(i >> 2) * (INF_WAVE * 4) + (i & 3)]; }
     __device__ __forceinline__ void clear_hi() const {
 #pragma unroll
         for (int k = 0; k < INF_N32; k++) b32[k * INF_WAVE] = 0u;
     }
     // litlen symbol (9 bits) at sorted position i
     __device__ __forceinline__ void put_litlen(uint32_t i, uint32_t sym) const {
-        b8[(L_SYM + (int)i) * INF_WAVE] = (uint8_t)sym;
+        sym8(L_SYM + (int)i) = (uint8_t)sym;
         if (sym >> 8) b32[(i >> 5) * INF_WAVE] |= 1u << (i & 31u);
     }
     __device__ __forceinline__ uint32_t get_litlen(uint32_t i) const {
-        const uint32_t lo = b8[(L_SYM + (int)i) * INF_WAVE], hi = b32[(i >> 5) * INF_WAVE];
+        const uint32_t lo = sym8(L_SYM + (int)i), hi = b32[(i >> 5) * INF_WAVE];
         return lo | (((hi >> (i & 31u)) & 1u) << 8);
     }
 };
@@ -338,14 +345,23 @@ __device__ uint32_t inflate_block(const uint8_t *comp, uint64_t comp_bytes, cons
             }
             // ---- the compressed data of this deflate block ------------------------------------
             for (;;) {
-                br.refill();
-                const int sym = huff_decode<15, true>(br, t, L_DELTA, L_SYM, 288, lu);
-                if (sym < 0) return INF_BAD_SYMBOL;
-                if (sym < 256) {
+                // Literal run first, in its own inner loop: a literal costs a decode and a fire-and-forget
+                // byte store, a match costs a load round trip -- and on a lock-stepped wave of 64 streams
+                // SOME lane has a match at nearly every step.  Letting every lane run through up to
+                // INF_LIT_RUN literals before the wave turns to the matches makes the round trip a cost
+                // per (literal run + match), not per token.
+                int sym;
+                uint32_t run = 0;
+                for (;;) {
+                    br.refill();
+                    sym = huff_decode<15, true>(br, t, L_DELTA, L_SYM, 288, lu);
+                    if (sym < 0 || sym >= 256) break;
                     if (pos >= isize) return INF_OVERRUN;
                     out[pos++] = (uint8_t)sym;
-                    continue;
+                    if (++run == INF_LIT_RUN) { sym = 512; break; }   // budget used up: give the matches their turn
                 }
+                if (sym < 0) return INF_BAD_SYMBOL;
+                if (sym == 512) continue;
                 if (sym == 256) break;
                 if (sym > 285) return INF_BAD_SYMBOL;
                 // length: 257..264 -> 3..10; 265..284 -> ((4 + (s-265)%4) << e) + 3 with e = (s-261)/4 extra bits; 285 -> 258
@@ -436,7 +452,7 @@ __global__ void __launch_bounds__(INF_WAVE) bgzf_inflate_kernel(const uint8_t *c
                                                                 uint32_t n_blocks, uint8_t *out) {
     extern __shared__ __attribute__((aligned(16))) uint8_t inf_lds[];
     const uint32_t lane = threadIdx.x;
-    const LaneLds t{(uint16_t *)inf_lds + lane, inf_lds + INF_N16 * 2 * INF_WAVE + lane,
+    const LaneLds t{inf_lds + 4u * lane, inf_lds + INF_N16 * 2 * INF_WAVE + 4u * lane,
                     (uint32_t *)(inf_lds + (INF_N16 * 2 + INF_N8) * INF_WAVE) + lane};
     for (uint32_t g = blockIdx.x; g * INF_WAVE < n_blocks; g += gridDim.x) {
         const uint32_t i = g * INF_WAVE + lane;
