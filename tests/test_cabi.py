@@ -58,3 +58,36 @@ def test_engine_refuses_without_gpu(pkg):
     with pytest.raises(pkg.PssbamError) as ei:
         pkg.Engine(pss=dict(region_len=15))
     assert "no HIP device" in str(ei.value) or "-2" in str(ei.value)
+
+
+def test_bgzf_scan_host_helper(pkg):
+    """pssbam_bgzf_scan (host code, no GPU): block table of a BGZF file -- payload offsets/lengths,
+    ISIZE, CRC, running output offsets -- checked against zlib block by block; partial trailing
+    block left to the caller; non-BGZF bytes refused"""
+    import ctypes as C
+    import zlib
+    import pssbam_testlib as tl
+
+    class Blk(C.Structure):
+        _fields_ = [("in_off", C.c_uint64), ("in_len", C.c_uint32), ("isize", C.c_uint32), ("out_off", C.c_uint64),
+                    ("crc", C.c_uint32), ("status", C.c_uint32)]
+    L = pkg.hip_lib()
+    L.pssbam_bgzf_scan.restype = C.c_int64
+    L.pssbam_bgzf_scan.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    raw = (ROOT / "tests" / "golden" / "setA.bam").read_bytes()
+    buf = np.frombuffer(raw, dtype=np.uint8)
+    consumed, total = C.c_uint64(), C.c_uint64()
+    n = L.pssbam_bgzf_scan(buf.ctypes.data, buf.size, None, 0, C.byref(consumed), C.byref(total))
+    assert n >= 2 and consumed.value == len(raw) and total.value == len(tl.bgzf_inflate(raw))
+    blocks = (Blk * n)()
+    assert L.pssbam_bgzf_scan(buf.ctypes.data, buf.size, blocks, n, None, None) == n
+    off = 0
+    for b in blocks:
+        data = zlib.decompress(raw[b.in_off:b.in_off + b.in_len], -15)
+        assert len(data) == b.isize and (zlib.crc32(data) & 0xFFFFFFFF) == b.crc and b.out_off == off
+        off += b.isize
+    # a cut-off last block is not counted, and its bytes are not consumed
+    m = L.pssbam_bgzf_scan(buf.ctypes.data, buf.size - 5, None, 0, C.byref(consumed), None)
+    assert m == n - 1 and consumed.value == len(raw) - 28      # (the last block is the 28-byte EOF marker)
+    junk = np.frombuffer(b"this is not a BGZF file at all, just some text" * 3, dtype=np.uint8)
+    assert L.pssbam_bgzf_scan(junk.ctypes.data, junk.size, None, 0, None, None) < 0
