@@ -236,16 +236,19 @@ int pssbam_bgzf_inflate_device(void *hip_stream, const void *d_comp, uint64_t co
 /* The whole feed in one call: a batch of whole BGZF blocks (compressed bytes in host memory,
  * page-locked for full PCIe speed; blocks[] from pssbam_bgzf_scan with in_off relative to comp and
  * out_off starting at 0, inflating to < 4 GiB) is copied, inflated, CRC-checked, record-indexed and
- * tallied on the device, asynchronously.  first_record_offset = bytes of the first block that come
- * before the first alignment record (the BAM header in the file's first batch, else 0).
+ * tallied on the device, asynchronously.  Consecutive calls continue ONE record stream (records may
+ * cross BGZF blocks and calls); first_record_offset = bytes of the stream's first block that come
+ * before the first alignment record (the BAM header; only in the first call after create / reset).
  * comp must stay untouched until pssbam_engine_wait_bgzf_copied(e, *ticket).  Whether the blocks
  * were sound is known once the work has run: pssbam_engine_feed_status. */
 int pssbam_engine_submit_bgzf(pssbam_engine *e, const void *comp, uint64_t comp_bytes, const pssbam_bgzf_block *blocks,
                               uint32_t n_blocks, uint32_t first_record_offset, uint64_t *ticket);
 int pssbam_engine_wait_bgzf_copied(pssbam_engine *e, uint64_t ticket);
 #define PSSBAM_FEED_BAD_BLOCK 1u   /* a block failed inflate / ISIZE / CRC-32                         */
-#define PSSBAM_FEED_RAGGED 2u      /* records cross BGZF blocks: use the host reader for this file     */
+#define PSSBAM_FEED_RAGGED 2u      /* the per-block record chains did not link up (or a record above 16 MiB):
+                                      use the host reader for this file                               */
 #define PSSBAM_FEED_BAD_RECORD 4u  /* an alignment record with block_size < 32                        */
+#define PSSBAM_FEED_TRUNCATED 8u   /* the stream ended inside an alignment record (as of the last sync) */
 int pssbam_engine_feed_status(pssbam_engine *e, uint32_t *flags, double *inflate_ms, uint64_t *inflated_bytes);
 /* Optional, before pssbam_engine_submit_bgzf / _submit_device: a few whole alignment records in host
  * memory (e.g. the first ones of the file) from which the tiled kernels' staged record prefix is

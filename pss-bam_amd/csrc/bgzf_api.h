@@ -243,6 +243,23 @@ static bool feed_take_reserved(int device, size_t comp_cap, uint8_t **comp, uint
     return false;
 }
 
+// buffers of a super-batch that do not depend on its contents
+static int feed_prepare(pssbam_engine *e, FeedAcc &s) {
+    if (!s.d_comp) {
+        s.comp_cap = (size_t)e->feed_comp_cap;
+        if (!feed_take_reserved(e->device, s.comp_cap, &s.d_comp, &s.d_out, &s.out_cap)) HIP_TRY(hipMalloc(&s.d_comp, s.comp_cap + 64));
+    }
+    if (!s.d_out) {
+        int rc = grow(&s.d_out, &s.out_cap, (size_t)(e->feed_out_target + FEED_OUT_SLACK));
+        if (rc) return rc;
+    }
+    if (!s.d_chain) {
+        HIP_TRY(hipMalloc(&s.d_chain, 2 * sizeof(uint64_t)));
+        HIP_TRY(hipMemsetAsync(s.d_chain, 0, 2 * sizeof(uint64_t), e->stream));
+    }
+    return PSSBAM_OK;
+}
+
 static int feed_flush(pssbam_engine *e) {
     FeedAcc &s = e->feed[e->cur_feed];
     if (s.blocks.empty()) return PSSBAM_OK;
@@ -251,13 +268,22 @@ static int feed_flush(pssbam_engine *e) {
     struct FlushTimer { pssbam_engine *e; double t0; ~FlushTimer() { e->feed_t_flush += feed_now() - t0; } } flush_timer{e, t_flush0};
     const size_t nb = s.blocks.size();
     if (nb > 0xFFFFFFF0ull) return fail(PSSBAM_EINVAL, "too many BGZF blocks in one super-batch");
-    size_t bc = s.blocks_cap, bc2 = s.blocks_cap, bc3 = s.blocks_cap;
-    if ((rc = grow((uint8_t **)&s.d_blocks, &bc, nb, sizeof(pssbam::BgzfBlock)))) return rc;
-    if ((rc = grow(&s.d_counts, &bc2, nb))) return rc;
-    if ((rc = grow(&s.d_base, &bc3, nb))) return rc;
-    s.blocks_cap = std::min(bc, std::min(bc2, bc3));
-    if ((rc = grow(&s.d_offs, &s.offs_cap, (size_t)(s.out_used / 36ull + 2ull * s.sub_first.size() + 16ull)))) return rc;
+    if (s.blocks_cap < nb) {
+        size_t c[8] = {s.blocks_cap, s.blocks_cap, s.blocks_cap, s.blocks_cap, s.blocks_cap, s.blocks_cap, s.blocks_cap, s.blocks_cap};
+        if ((rc = grow((uint8_t **)&s.d_blocks, &c[0], nb, sizeof(pssbam::BgzfBlock)))) return rc;
+        if ((rc = grow(&s.d_a, &c[1], nb))) return rc;
+        if ((rc = grow(&s.d_e, &c[2], nb))) return rc;
+        if ((rc = grow(&s.d_last, &c[3], nb))) return rc;
+        if ((rc = grow(&s.d_nexta, &c[4], nb + 1))) return rc;
+        if ((rc = grow(&s.d_n, &c[5], nb))) return rc;
+        if ((rc = grow(&s.d_counts, &c[6], nb))) return rc;
+        if ((rc = grow(&s.d_base, &c[7], nb))) return rc;
+        s.blocks_cap = *std::min_element(c, c + 8);
+    }
+    const uint64_t data_end = s.out_used;   // the blocks sit contiguously in [FEED_GAP, data_end)
+    if ((rc = grow(&s.d_offs, &s.offs_cap, (size_t)(data_end / 36ull + 2ull * s.sub_first.size() + 16ull)))) return rc;
     if ((rc = grow(&s.d_nrecs, &s.nrecs_cap, s.sub_first.size()))) return rc;
+    if ((rc = feed_prepare(e, e->feed[e->cur_feed ^ 1]))) return rc;   // the tail goes into the other super-batch's gap
     // every chunk of this super-batch has been issued on the copy streams: the engine's stream waits for them
     if (!s.copies_done) {
         HIP_TRY(hipEventCreateWithFlags(&s.copies_done, hipEventDisableTiming));
@@ -268,40 +294,62 @@ static int feed_flush(pssbam_engine *e) {
     HIP_TRY(hipStreamWaitEvent(e->stream, s.copies_done, 0));
     HIP_TRY(hipStreamWaitEvent(e->stream, s.copies_done2, 0));
     HIP_TRY(hipMemcpyAsync(s.d_blocks, s.blocks.data(), nb * sizeof(pssbam_bgzf_block), hipMemcpyHostToDevice, e->stream));
+    if (e->feed_fresh) {   // the stream's first super-batch: its chain starts behind the BAM header
+        const uint64_t first = FEED_GAP + e->feed_skip;
+        HIP_TRY(hipMemcpyAsync(s.d_chain, &first, sizeof first, hipMemcpyHostToDevice, e->stream));   // (pageable source: copied before the call returns)
+        e->feed_fresh = false;
+    }
     hipEvent_t ev0 = take_event(e), ev1 = take_event(e);
     if (!ev0 || !ev1) return fail(PSSBAM_EHIP, "hipEventCreate failed");
     HIP_TRY(hipEventRecord(ev0, e->stream));
     rc = pssbam_bgzf_inflate_device(e->stream, s.d_comp, s.comp_used, (pssbam_bgzf_block *)s.d_blocks, (uint32_t)nb, s.d_out,
                                     getenv("PSSBAM_NO_CRC") ? 0 : 1);
     if (rc) return rc;
-    // record index per sub-batch
+    // the record chain of the whole super-batch: per-block pieces, linked and checked
+    {
+        const uint32_t n = (uint32_t)nb, grid = std::min<uint32_t>((n + 255u) / 256u, (uint32_t)e->n_cu * 8u);
+        const pssbam::BgzfBlock *blk = (const pssbam::BgzfBlock *)s.d_blocks;
+        hipLaunchKernelGGL(pssbam::bgzf_chain_spec, dim3(grid), dim3(256), 0, e->stream, (const uint8_t *)s.d_out, blk, n, data_end,
+                           (const uint64_t *)s.d_chain, e->n_ref, s.d_a, s.d_n, s.d_e, s.d_last, e->d_feed_flags);
+        hipLaunchKernelGGL(pssbam::bgzf_chain_suffix, dim3(1), dim3(1024), 0, e->stream, (const uint64_t *)s.d_a, n, s.d_nexta);
+        hipLaunchKernelGGL(pssbam::bgzf_chain_verify, dim3(grid), dim3(256), 0, e->stream, (const uint8_t *)s.d_out, (const uint32_t *)s.d_n, (const uint64_t *)s.d_e,
+                           (const uint64_t *)s.d_last, (const uint64_t *)s.d_nexta, n, data_end, (const uint64_t *)s.d_chain, s.d_counts,
+                           s.d_chain + 1, e->d_feed_flags);
+    }
+    // offsets per tally sub-batch: the records STARTING in its blocks, relative to a 16-byte aligned base
     uint64_t offs_at = 0;
     std::vector<uint64_t> sub_offs(s.sub_first.size()), sub_base(s.sub_first.size()), sub_len(s.sub_first.size());
     for (size_t k = 0; k < s.sub_first.size(); k++) {
         const uint32_t b0 = s.sub_first[k], b1 = k + 1 < s.sub_first.size() ? s.sub_first[k + 1] : (uint32_t)nb;
-        const uint64_t base = s.blocks[b0].out_off, len = s.blocks[b1 - 1].out_off + s.blocks[b1 - 1].isize - base;
+        // (sub-batch 0 owns the carried record in the gap; a later one may be entered by the last record of its predecessor)
+        const uint64_t base = k == 0 ? 0ull : (s.blocks[b0].out_off & ~15ull);
+        const uint64_t end = std::min<uint64_t>(data_end, s.blocks[b1 - 1].out_off + s.blocks[b1 - 1].isize + FEED_GAP);
         sub_offs[k] = offs_at;
         sub_base[k] = base;
-        sub_len[k] = len;
+        sub_len[k] = end - base;
         const uint32_t n = b1 - b0;
         const uint32_t igrid = std::min<uint32_t>((n + 255u) / 256u, (uint32_t)e->n_cu * 8u);
-        const pssbam::BgzfBlock *blk = (const pssbam::BgzfBlock *)s.d_blocks + b0;
-        hipLaunchKernelGGL(pssbam::bgzf_index_count, dim3(igrid), dim3(256), 0, e->stream, (const uint8_t *)s.d_out, blk, n, s.sub_skip[k],
-                           s.d_counts + b0, e->d_feed_flags);
         hipLaunchKernelGGL(pssbam::bgzf_index_scan, dim3(1), dim3(1024), 0, e->stream, (const uint32_t *)(s.d_counts + b0), n, s.d_base + b0,
                            s.d_nrecs + k);
-        hipLaunchKernelGGL(pssbam::bgzf_index_write, dim3(igrid), dim3(256), 0, e->stream, (const uint8_t *)s.d_out, blk, n, s.sub_skip[k],
-                           (const uint32_t *)(s.d_counts + b0), (const uint32_t *)(s.d_base + b0), s.d_offs + offs_at, (const uint32_t *)(s.d_nrecs + k),
-                           base, (uint32_t)len);
-        offs_at += len / 36ull + 2ull;
+        hipLaunchKernelGGL(pssbam::bgzf_chain_write, dim3(igrid), dim3(256), 0, e->stream, (const uint8_t *)s.d_out, (const uint64_t *)(s.d_a + b0),
+                           (const uint32_t *)(s.d_counts + b0), (const uint32_t *)(s.d_base + b0), n, base, s.d_offs + offs_at,
+                           (const uint32_t *)(s.d_nrecs + k));
+        offs_at += sub_len[k] / 36ull + 2ull;
+    }
+    // the partial record at the end moves in front of the next super-batch's data
+    {
+        FeedAcc &o = e->feed[e->cur_feed ^ 1];
+        hipLaunchKernelGGL(pssbam::bgzf_chain_carry, dim3(1), dim3(256), 0, e->stream, (const uint8_t *)s.d_out, (const uint64_t *)(s.d_chain + 1), data_end,
+                           o.d_out, (uint64_t)FEED_GAP, o.d_chain, e->d_feed_tail, e->d_feed_flags);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev1, e->stream));
     e->inflate_events.emplace_back(ev0, ev1);
-    e->inflated_bytes += s.out_used;
+    e->inflated_bytes += data_end - FEED_GAP;
     for (size_t k = 0; k < s.sub_first.size(); k++) {
         rc = launch_tally(e, s.d_out + sub_base[k], sub_len[k], s.d_offs + sub_offs[k],
-                          (uint32_t)std::min<uint64_t>(sub_len[k] / 36ull + 2ull, 0xFFFFFFF0ull), nullptr, 0, s.d_nrecs + k, s.sub_skip[k]);
+                          (uint32_t)std::min<uint64_t>(sub_len[k] / 36ull + 2ull, 0xFFFFFFF0ull), nullptr, 0, s.d_nrecs + k,
+                          k == 0 ? FEED_GAP : 0ull);
         if (rc) return rc;
     }
     if (!s.consumed) HIP_TRY(hipEventCreateWithFlags(&s.consumed, hipEventDisableTiming));
@@ -309,15 +357,13 @@ static int feed_flush(pssbam_engine *e) {
     s.busy = true;
     s.blocks.clear();
     s.sub_first.clear();
-    s.sub_skip.clear();
     s.comp_used = s.out_used = s.sub_bytes = 0;
     e->cur_feed ^= 1;
     return PSSBAM_OK;
 }
 
 // appends blocks[b0, b1) of a chunk (and their compressed bytes) to the super-batch being assembled
-static int feed_append(pssbam_engine *e, const uint8_t *comp, const pssbam_bgzf_block *blocks, uint32_t b0, uint32_t b1,
-                       uint32_t first_record_offset, hipStream_t cs) {
+static int feed_append(pssbam_engine *e, const uint8_t *comp, const pssbam_bgzf_block *blocks, uint32_t b0, uint32_t b1, hipStream_t cs) {
     FeedAcc &s = e->feed[e->cur_feed];
     int rc;
     if (s.busy) {   // its previous super-batch must have been consumed before its buffers are overwritten
@@ -327,29 +373,20 @@ static int feed_append(pssbam_engine *e, const uint8_t *comp, const pssbam_bgzf_
         s.busy = false;
     }
     const double t_alloc0 = feed_now();
-    if (!s.d_comp) {
-        s.comp_cap = (size_t)e->feed_comp_cap;
-        if (!feed_take_reserved(e->device, s.comp_cap, &s.d_comp, &s.d_out, &s.out_cap)) HIP_TRY(hipMalloc(&s.d_comp, s.comp_cap + 64));
-    }
+    if ((rc = feed_prepare(e, s))) return rc;
+    e->feed_t_alloc += feed_now() - t_alloc0;
+    if (s.blocks.empty()) s.out_used = FEED_GAP;
     const uint64_t byte0 = blocks[b0].in_off & ~15ull, byte1 = blocks[b1 - 1].in_off + blocks[b1 - 1].in_len;
     const uint64_t out_bytes = blocks[b1 - 1].out_off + blocks[b1 - 1].isize - blocks[b0].out_off;
-    if (s.out_cap < s.out_used + out_bytes + 8192) {
-        if (s.out_used) return fail(PSSBAM_ESTATE, "output buffer of the super-batch cannot grow while it holds blocks");
-        const uint64_t need_out = std::max<uint64_t>(e->feed_out_target, out_bytes) + FEED_OUT_SLACK;
-        if ((rc = grow(&s.d_out, &s.out_cap, (size_t)need_out))) return rc;
-    }
-    e->feed_t_alloc += feed_now() - t_alloc0;
-    // blocks: in_off -> into d_comp, out_off -> into d_out; a new tally sub-batch where the record
-    // bytes would pass 3.5 GiB or where bytes must be skipped in front of the first record
+    if (s.out_cap < s.out_used + out_bytes + 8192) return fail(PSSBAM_ESTATE, "output buffer of the super-batch is too small");
+    // blocks: in_off -> into d_comp, out_off -> into d_out, back to back (records may cross blocks); a new
+    // tally sub-batch where the record bytes would pass 3.5 GiB
     const uint64_t comp_at = (s.comp_used + 15ull) & ~15ull;
     if (comp_at + (byte1 - byte0) + 32 > s.comp_cap) return fail(PSSBAM_ESTATE, "compressed bytes of the super-batch exceed their buffer");
     for (uint32_t i = b0; i < b1; i++) {
         pssbam_bgzf_block b = blocks[i];
-        const bool new_sub = s.sub_first.empty() || (i == b0 && first_record_offset) || s.sub_bytes + b.isize > FEED_SUB_MAX;
-        if (new_sub) {
-            s.out_used = (s.out_used + 255ull) & ~255ull;   // a tally launch wants its records 16-byte aligned
+        if (s.sub_first.empty() || s.sub_bytes + b.isize > FEED_SUB_MAX) {
             s.sub_first.push_back((uint32_t)s.blocks.size());
-            s.sub_skip.push_back(i == b0 ? first_record_offset : 0u);
             s.sub_bytes = 0;
         }
         b.in_off = b.in_off - byte0 + comp_at;
@@ -377,6 +414,9 @@ extern "C" int pssbam_engine_submit_bgzf(pssbam_engine *e, const void *comp, uin
     if (out_bytes > (1ull << 30)) return fail(PSSBAM_EINVAL, "chunk inflates to %llu bytes; keep chunks at or below 1 GiB", (unsigned long long)out_bytes);
     if (blocks[0].out_off != 0) return fail(PSSBAM_EINVAL, "blocks[0].out_off must be 0");
     if (first_record_offset > blocks[0].isize) return fail(PSSBAM_EINVAL, "first_record_offset lies beyond the first block");
+    if (first_record_offset && !(e->feed_fresh && e->feed[0].blocks.empty() && e->feed[1].blocks.empty()))
+        return fail(PSSBAM_ESTATE, "first_record_offset only makes sense for the first blocks of a stream (after create / reset)");
+    if (first_record_offset) e->feed_skip = first_record_offset;
     if (comp_bytes > e->feed_comp_cap / 2) return fail(PSSBAM_EINVAL, "chunk of %llu compressed bytes is too large", (unsigned long long)comp_bytes);
     HIP_TRY(hipSetDevice(e->device));
     if (!e->d_feed_flags) {
@@ -388,6 +428,8 @@ extern "C" int pssbam_engine_submit_bgzf(pssbam_engine *e, const void *comp, uin
         e->feed_block_target = getenv("PSSBAM_FEED_SUPER_BYTES") && e->feed_out_target < lanes * 65280ull ? 0xFFFFFFFFull : rounds * lanes;
         HIP_TRY(hipMalloc(&e->d_feed_flags, sizeof(uint32_t)));
         HIP_TRY(hipMemsetAsync(e->d_feed_flags, 0, sizeof(uint32_t), e->stream));
+        HIP_TRY(hipMalloc(&e->d_feed_tail, sizeof(uint64_t)));
+        HIP_TRY(hipMemsetAsync(e->d_feed_tail, 0, sizeof(uint64_t), e->stream));
     }
     hipStream_t cs = (e->ticket_seq & 1u) ? e->copy_stream2 : e->copy_stream;
     uint32_t b0 = 0;
@@ -404,7 +446,7 @@ extern "C" int pssbam_engine_submit_bgzf(pssbam_engine *e, const void *comp, uin
         const uint64_t comp0 = blocks[b0].in_off & ~15ull, out0 = blocks[b0].out_off;
         while (b1 < n_blocks && cur.blocks.size() + (b1 - b0) < block_target &&
                cur.out_used + (blocks[b1].out_off + blocks[b1].isize - out0) + 512 <= byte_target + (1ull << 30) &&
-               cur.out_used + (blocks[b1].out_off + blocks[b1].isize - out0) + 8192 <= std::max<uint64_t>(cur.out_cap, e->feed_out_target + FEED_OUT_SLACK) &&
+               std::max<uint64_t>(cur.out_used, FEED_GAP) + (blocks[b1].out_off + blocks[b1].isize - out0) + 8192 <= std::max<uint64_t>(cur.out_cap, e->feed_out_target + FEED_OUT_SLACK) &&
                cur.comp_used + (blocks[b1].in_off + blocks[b1].in_len - comp0) + 64 <= e->feed_comp_cap)
             b1++;
         if (b1 == b0) {
@@ -413,7 +455,7 @@ extern "C" int pssbam_engine_submit_bgzf(pssbam_engine *e, const void *comp, uin
             if (rc) return rc;
             continue;
         }
-        rc = feed_append(e, (const uint8_t *)comp, blocks, b0, b1, b0 == 0 ? first_record_offset : 0u, cs);
+        rc = feed_append(e, (const uint8_t *)comp, blocks, b0, b1, cs);
         if (rc) return rc;
         b0 = b1;
         if (e->feed[e->cur_feed].blocks.size() >= block_target || e->feed[e->cur_feed].out_used >= byte_target) {
@@ -456,6 +498,11 @@ extern "C" int pssbam_engine_feed_status(pssbam_engine *e, uint32_t *flags, doub
     if (rc) return rc;
     uint32_t f = 0;
     if (e->d_feed_flags) HIP_TRY(hipMemcpy(&f, e->d_feed_flags, sizeof f, hipMemcpyDeviceToHost));
+    if (e->d_feed_tail) {   // a record cut off by the end of the stream
+        uint64_t tail = 0;
+        HIP_TRY(hipMemcpy(&tail, e->d_feed_tail, sizeof tail, hipMemcpyDeviceToHost));
+        if (tail) f |= pssbam::FEED_TRUNCATED;
+    }
     for (auto &p : e->inflate_events) {
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, p.first, p.second));

@@ -80,25 +80,28 @@ struct Slot {  // one in-flight host-submitted block
 };
 
 // per super-batch: output of two rounds of the inflate kernel's 81 920 lanes (2 x 5.35 GB), and room for its compressed bytes
-static constexpr uint64_t FEED_OUT_TARGET = 10800ull << 20, FEED_COMP_CAP = 2ull << 30, FEED_OUT_SLACK = (1ull << 30) + (64ull << 20);
+static constexpr uint64_t FEED_OUT_TARGET = 10800ull << 20, FEED_COMP_CAP = 2ull << 30, FEED_OUT_SLACK = (1ull << 30) + (64ull << 20),
+                          FEED_GAP = 16ull << 20;   // room in front of a super-batch's data for the record the previous one ended in
 
 struct FeedAcc {  // one super-batch of compressed blocks: assembled chunk by chunk, then inflated in ONE launch
     uint8_t *d_comp = nullptr;      // compressed bytes of the chunks, back to back (each 16-byte aligned)
     size_t comp_cap = 0;
     uint64_t comp_used = 0;
-    std::vector<pssbam_bgzf_block> blocks;   // in_off into d_comp, out_off into d_out
+    std::vector<pssbam_bgzf_block> blocks;   // in_off into d_comp, out_off into d_out (contiguous from FEED_GAP on)
     std::vector<uint32_t> sub_first;         // first block of every tally sub-batch (< 4 GiB of records each)
-    std::vector<uint32_t> sub_skip;          // bytes in front of the first record of that block (BAM header)
     uint64_t out_used = 0, sub_bytes = 0;
     void *d_blocks = nullptr;                // pssbam::BgzfBlock[]
-    uint32_t *d_counts = nullptr, *d_base = nullptr;
+    // per block: chain pieces (first record start, records, end, last record start), suffix minimum, counts, bases
+    uint64_t *d_a = nullptr, *d_e = nullptr, *d_last = nullptr, *d_nexta = nullptr;
+    uint32_t *d_n = nullptr, *d_counts = nullptr, *d_base = nullptr;
     size_t blocks_cap = 0;
-    uint8_t *d_out = nullptr;
+    uint8_t *d_out = nullptr;                // [0, FEED_GAP): the partial record carried over from the previous super-batch
     size_t out_cap = 0;
     uint32_t *d_offs = nullptr;
     size_t offs_cap = 0;
     uint32_t *d_nrecs = nullptr;
     size_t nrecs_cap = 0;
+    uint64_t *d_chain = nullptr;             // [0] where this super-batch's chain starts, [1] where its tail starts
     hipEvent_t consumed = nullptr, copies_done = nullptr, copies_done2 = nullptr;
     bool busy = false;
 };
@@ -149,6 +152,9 @@ struct pssbam_engine {
     std::vector<std::pair<uint64_t, hipEvent_t>> feed_copies;             // (ticket, copy-complete event) of submits
     std::vector<hipEvent_t> feed_event_pool;
     uint32_t *d_feed_flags = nullptr;
+    uint64_t *d_feed_tail = nullptr;   // bytes of the partial record the last flushed super-batch ended with
+    bool feed_fresh = true;            // nothing of the current stream has been flushed yet
+    uint32_t feed_skip = 0;            // inflated bytes in front of the stream's first record (the BAM header)
     double inflate_ms = 0.0;  // summed inflate + CRC + index kernel durations
     uint64_t inflated_bytes = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> inflate_events;
@@ -282,17 +288,14 @@ extern "C" void pssbam_engine_destroy(pssbam_engine *e) {
         if (s.consumed) (void)hipEventDestroy(s.consumed);
     }
     for (FeedAcc &s : e->feed) {
-        if (s.d_comp) (void)hipFree(s.d_comp);
-        if (s.d_blocks) (void)hipFree(s.d_blocks);
-        if (s.d_counts) (void)hipFree(s.d_counts);
-        if (s.d_base) (void)hipFree(s.d_base);
-        if (s.d_out) (void)hipFree(s.d_out);
-        if (s.d_offs) (void)hipFree(s.d_offs);
-        if (s.d_nrecs) (void)hipFree(s.d_nrecs);
+        void *ptrs[] = {s.d_comp, s.d_blocks, s.d_a, s.d_e, s.d_last, s.d_nexta, s.d_n, s.d_counts, s.d_base, s.d_out, s.d_offs, s.d_nrecs, s.d_chain};
+        for (void *q : ptrs)
+            if (q) (void)hipFree(q);
         if (s.consumed) (void)hipEventDestroy(s.consumed);
         if (s.copies_done) (void)hipEventDestroy(s.copies_done);
         if (s.copies_done2) (void)hipEventDestroy(s.copies_done2);
     }
+    if (e->d_feed_tail) (void)hipFree(e->d_feed_tail);
     for (auto &p : e->feed_copies) (void)hipEventDestroy(p.second);
     for (hipEvent_t ev : e->feed_event_pool) (void)hipEventDestroy(ev);
     if (e->d_feed_flags) (void)hipFree(e->d_feed_flags);
@@ -891,6 +894,10 @@ extern "C" int pssbam_engine_finish(pssbam_engine *e, unsigned long *fwd, unsign
 extern "C" int pssbam_engine_reset(pssbam_engine *e) {
     if (!e) return fail(PSSBAM_EINVAL, "null engine");
     HIP_TRY(hipSetDevice(e->device));
+    e->feed_fresh = true;   // a compressed stream fed from here on starts a new record chain
+    e->feed_skip = 0;
+    if (e->d_feed_tail) HIP_TRY(hipMemsetAsync(e->d_feed_tail, 0, sizeof(uint64_t), e->stream));
+    if (e->d_feed_flags) HIP_TRY(hipMemsetAsync(e->d_feed_flags, 0, sizeof(uint32_t), e->stream));
     HIP_TRY(hipMemsetAsync(e->d_counters, 0, e->n_counters * sizeof(unsigned long long), e->stream));
     return PSSBAM_OK;
 }

@@ -537,16 +537,22 @@ __global__ void __launch_bounds__(256) bgzf_crc_kernel(const uint8_t *out, BgzfB
 
 
 // ---------------------------------------------------------------------------------------
-// record index of an inflated batch, on the device
+// record index of an inflated super-batch, on the device
 // ---------------------------------------------------------------------------------------
-// The tally kernels want a u32 offset per alignment record.  In files written by htslib every
-// BGZF block starts on a record boundary (bgzf_flush_try before a record that would not fit), so
-// the block_size chains of the blocks are independent: a lane per block counts its records, a
-// scan turns the counts into bases, a second walk writes the offsets.  A block whose chain does
-// not end exactly at its ISIZE (htsjdk-style layout, or a record larger than a block) raises
-// FEED_RAGGED and the caller falls back to the host reader, whose indexer follows the chain
-// across blocks.
-enum : uint32_t { FEED_BAD_BLOCK = 1u, FEED_RAGGED = 2u, FEED_BAD_RECORD = 4u };
+// The tally kernels want a u32 offset per alignment record, i.e. the block_size chain of the BAM
+// stream -- a serial chain.  It is cut at the BGZF blocks: every block's lane looks for the first
+// offset in ITS block from which a chain of plausible records runs to the block's end (offset 0 in
+// files written by htslib, whose blocks start on record boundaries; somewhere in the first record's
+// length in files written by htsjdk, whose records cross blocks), walks it, and reports where its
+// last record ends.  A verification pass then checks that every block's chain ends exactly where the
+// next block's begins; if so the pieces ARE the chain, and counts -> scan -> offsets follow in
+// parallel.  If not (a false start, a block inside a record longer than a block whose neighbours
+// disagree, ...) FEED_RAGGED is raised and the caller falls back to the host reader, whose indexer
+// walks serially.  The partial record a super-batch ends with is copied in front of the next
+// super-batch's data (bgzf_chain_carry), whose block 0 starts its walk there.
+enum : uint32_t { FEED_BAD_BLOCK = 1u, FEED_RAGGED = 2u, FEED_BAD_RECORD = 4u, FEED_TRUNCATED = 8u };
+constexpr uint64_t CHAIN_NONE = ~0ull;
+constexpr uint32_t CHAIN_MAX_RECORD = 1u << 24;   // records above 16 MiB (the carry gap) go the host way
 
 __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t *p) {
     uint32_t v;
@@ -554,25 +560,127 @@ __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t *p) {
     return v;
 }
 
-__global__ void __launch_bounds__(256) bgzf_index_count(const uint8_t *out, const BgzfBlock *blocks, uint32_t n_blocks,
-                                                        uint32_t first_off, uint32_t *counts, uint32_t *flags) {
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_blocks; i += gridDim.x * blockDim.x) {
-        const BgzfBlock b = blocks[i];
-        uint32_t n = 0u;
-        if (b.status != INF_OK) atomicOr(flags, FEED_BAD_BLOCK);
+// the layout arithmetic of SAM spec 4.2 + value ranges (host twin: plausible_record, bam_reader.c)
+__device__ __forceinline__ bool plausible_record(const uint8_t *p, uint64_t avail, int32_t n_ref) {
+    if (avail < 36u) return false;
+    const uint32_t bs = load_u32_unaligned(p);
+    const int32_t ref_id = (int32_t)load_u32_unaligned(p + 4), pos = (int32_t)load_u32_unaligned(p + 8);
+    const uint32_t w3 = load_u32_unaligned(p + 12), w4 = load_u32_unaligned(p + 16), l_seq = load_u32_unaligned(p + 20);
+    const int32_t next_ref = (int32_t)load_u32_unaligned(p + 24), next_pos = (int32_t)load_u32_unaligned(p + 28);
+    const uint32_t l_name = w3 & 0xFFu, n_cig = w4 & 0xFFFFu;
+    if (bs < 32u || bs > CHAIN_MAX_RECORD || l_name == 0u) return false;
+    if (ref_id < -1 || ref_id >= n_ref || next_ref < -1 || next_ref >= n_ref || pos < -1 || next_pos < -1) return false;
+    if (l_seq > bs) return false;
+    if (32ull + l_name + 4ull * n_cig + ((uint64_t)l_seq + 1ull) / 2ull + l_seq > bs) return false;
+    if (36ull + l_name <= avail && p[36u + l_name - 1u] != 0u) return false;   // the read name is NUL-terminated
+    return true;
+}
+
+// per block: a = absolute offset of the first record starting in it (CHAIN_NONE: none), n = records
+// starting in it, e = where the last of them ends, last = where the last of them starts
+__global__ void __launch_bounds__(256) bgzf_chain_spec(const uint8_t *out, const BgzfBlock *blocks, uint32_t n_blocks, uint64_t data_end,
+                                                       const uint64_t *first_start, int32_t n_ref, uint64_t *a, uint32_t *n,
+                                                       uint64_t *e, uint64_t *last, uint32_t *flags) {
+    for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < n_blocks; b += gridDim.x * blockDim.x) {
+        const BgzfBlock blk = blocks[b];
+        uint64_t a_b = CHAIN_NONE, e_b = 0, last_b = 0;
+        uint32_t n_b = 0;
+        if (blk.status != INF_OK) atomicOr(flags, FEED_BAD_BLOCK);
         else {
-            const uint8_t *p = out + b.out_off;
-            uint32_t o = i == 0u ? first_off : 0u;
-            while (o + 4u <= b.isize) {
-                const uint32_t bs = load_u32_unaligned(p + o);
-                if (bs < 32u) { atomicOr(flags, FEED_BAD_RECORD); o = b.isize; break; }
-                if (bs > b.isize - o - 4u) break;   // runs past the block
-                o += 4u + bs;
-                n++;
+            const uint64_t lo = blk.out_off, hi = lo + blk.isize;
+            if (b == 0u) {
+                // the chain's known position: the carried partial record (in the gap in front of the data), or
+                // the first byte behind the BAM header
+                uint64_t o = *first_start;
+                a_b = o;
+                while (o < hi && o + 4u <= data_end) {
+                    const uint32_t bs = load_u32_unaligned(out + o);
+                    if (bs < 32u || bs > CHAIN_MAX_RECORD) { atomicOr(flags, bs < 32u ? FEED_BAD_RECORD : FEED_RAGGED); break; }
+                    last_b = o;
+                    o += 4ull + bs;
+                    n_b++;
+                }
+                e_b = o;
+                if (!n_b) a_b = CHAIN_NONE;
+            } else {
+                // (the bytes behind the block's end are the next block's: the buffer is contiguous, so a record
+                //  that starts in the last bytes of the block can be judged too; a candidate must also
+                //  survive two records beyond the block -- with small blocks its own record says little)
+                uint32_t tries = 0;
+                for (uint64_t c = lo; c < hi && tries < 4u; c++) {
+                    if (!plausible_record(out + c, data_end - c, n_ref)) continue;
+                    tries++;
+                    uint64_t o = c, l = c, end_in = c;
+                    uint32_t k = 0, extra = 0;
+                    bool good = true;
+                    for (;;) {
+                        if (o + 4u > data_end) break;   // the length word itself is cut off: the tail
+                        const uint32_t bs = load_u32_unaligned(out + o);
+                        // a record cut off by the end of the data cannot be judged by its fields: its length decides
+                        const bool near_end = data_end - o < 36u + 256u;
+                        if (!(plausible_record(out + o, data_end - o, n_ref) || (near_end && bs >= 32u && bs <= CHAIN_MAX_RECORD))) { good = false; break; }
+                        if (o < hi) { k++; l = o; end_in = o + 4ull + bs; }
+                        else if (++extra >= 2u) break;
+                        o += 4ull + bs;
+                        if (o >= data_end) break;
+                    }
+                    if (good && k) { a_b = c; n_b = k; e_b = end_in; last_b = l; break; }
+                }
             }
-            if (o != b.isize) atomicOr(flags, FEED_RAGGED);
         }
-        counts[i] = n;
+        a[b] = a_b;
+        n[b] = n_b;
+        e[b] = e_b;
+        last[b] = last_b;
+    }
+}
+
+// nexta[b] = the first record start at or after block b (suffix minimum of a[]; a[] grows with b), nexta[n] = NONE
+__global__ void __launch_bounds__(1024) bgzf_chain_suffix(const uint64_t *a, uint32_t n, uint64_t *nexta) {
+    __shared__ uint64_t part[1024];
+    const uint32_t t = threadIdx.x, per = (n + 1023u) / 1024u;
+    const uint32_t lo = min(n, t * per), hi = min(n, lo + per);
+    uint64_t m = CHAIN_NONE;
+    for (uint32_t i = lo; i < hi; i++) m = min(m, a[i]);
+    part[t] = m;
+    __syncthreads();
+    for (uint32_t d = 1u; d < 1024u; d <<= 1) {   // suffix minimum over the strips
+        const uint64_t v = t + d < 1024u ? part[t + d] : CHAIN_NONE;
+        __syncthreads();
+        part[t] = min(part[t], v);
+        __syncthreads();
+    }
+    uint64_t run = t + 1u < 1024u ? part[t + 1u] : CHAIN_NONE;   // everything behind this strip
+    for (uint32_t i = hi; i > lo; i--) { run = min(run, a[i - 1u]); nexta[i - 1u] = run; }
+    if (t == 0u) nexta[n] = CHAIN_NONE;
+}
+
+// checks that the per-block chains link up, settles the records of the last block against the end of
+// the data (an incomplete last record is the tail), writes counts[] and the tail's start
+__global__ void __launch_bounds__(256) bgzf_chain_verify(const uint8_t *out, const uint32_t *n, const uint64_t *e, const uint64_t *last,
+                                                         const uint64_t *nexta, uint32_t n_blocks, uint64_t data_end, const uint64_t *first_start,
+                                                         uint32_t *counts, uint64_t *tail_start, uint32_t *flags) {
+    for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < n_blocks; b += gridDim.x * blockDim.x) {
+        uint32_t c = n[b];
+        if (c) {
+            const uint64_t next = nexta[b + 1u];
+            if (next != CHAIN_NONE) {
+                if (e[b] != next) atomicOr(flags, FEED_RAGGED);
+            } else if (e[b] == data_end) *tail_start = data_end;
+            else if (e[b] > data_end) { c--; *tail_start = last[b]; }       // the last record runs past the data: the tail
+            else if (data_end - e[b] < 4u) *tail_start = e[b];             // a cut-off length word: the tail
+            else {
+                // a record starts at e[b] that no block claimed (too little of it is there to be judged by its
+                // fields): fine if it is the cut-off tail, a broken chain if it is whole
+                const uint32_t bs = load_u32_unaligned(out + e[b]);
+                if (bs >= 32u && bs <= CHAIN_MAX_RECORD && e[b] + 4ull + bs > data_end) *tail_start = e[b];
+                else atomicOr(flags, FEED_RAGGED);
+            }
+        }
+        counts[b] = c;
+        if (b == 0u && nexta[0] == CHAIN_NONE) {   // not one record starts in this super-batch: all of it is tail
+            *tail_start = *first_start;
+        }
     }
 }
 
@@ -596,21 +704,34 @@ __global__ void __launch_bounds__(1024) bgzf_index_scan(const uint32_t *counts, 
     if (t == 1023u) *total = part[1023];
 }
 
-__global__ void __launch_bounds__(256) bgzf_index_write(const uint8_t *out, const BgzfBlock *blocks, uint32_t n_blocks,
-                                                        uint32_t first_off, const uint32_t *counts, const uint32_t *base,
-                                                        uint32_t *offs, const uint32_t *total, uint64_t batch_base,
-                                                        uint32_t batch_bytes) {
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_blocks; i += gridDim.x * blockDim.x) {
-        const BgzfBlock b = blocks[i];
-        const uint8_t *p = out + b.out_off;
-        uint32_t o = i == 0u ? first_off : 0u, k = base[i];
-        const uint32_t k_end = k + counts[i];
-        while (k < k_end) {   // the same walk as bgzf_index_count, bounded by its count
-            offs[k++] = (uint32_t)(b.out_off - batch_base) + o;   // relative to the tally launch's record base
-            o += 4u + load_u32_unaligned(p + o);
+// offsets of the records of one tally sub-batch (blocks [0, n_blocks) of the arrays handed in), relative
+// to the sub-batch's record base; the block that holds the sub-batch's last record also writes the
+// end sentinel
+__global__ void __launch_bounds__(256) bgzf_chain_write(const uint8_t *out, const uint64_t *a, const uint32_t *counts, const uint32_t *base,
+                                                        uint32_t n_blocks, uint64_t sub_base, uint32_t *offs, const uint32_t *total) {
+    for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < n_blocks; b += gridDim.x * blockDim.x) {
+        const uint32_t c = counts[b];
+        if (!c) continue;
+        uint64_t o = a[b];
+        uint32_t k = base[b];
+        for (uint32_t i = 0; i < c; i++) {
+            offs[k++] = (uint32_t)(o - sub_base);
+            o += 4ull + load_u32_unaligned(out + o);
         }
-        if (i == n_blocks - 1u) offs[*total] = batch_bytes;
+        if (k == *total) offs[k] = (uint32_t)(o - sub_base);
     }
+}
+
+// the partial record a super-batch ends with goes in front of the next super-batch's data
+__global__ void __launch_bounds__(256) bgzf_chain_carry(const uint8_t *src_out, const uint64_t *tail_start, uint64_t data_end, uint8_t *dst_out,
+                                                        uint64_t gap, uint64_t *next_first_start, uint64_t *tail_len_out, uint32_t *flags) {
+    const uint64_t from = *tail_start, len = data_end > from ? data_end - from : 0ull;
+    if (len > gap) {
+        if (threadIdx.x == 0) { atomicOr(flags, FEED_RAGGED); *next_first_start = gap; *tail_len_out = 0; }
+        return;
+    }
+    for (uint64_t i = threadIdx.x; i < len; i += blockDim.x) dst_out[gap - len + i] = src_out[from + i];
+    if (threadIdx.x == 0) { *next_first_start = gap - len; *tail_len_out = len; }
 }
 
 }  // namespace pssbam

@@ -13,9 +13,10 @@
  *                    cuts batches that inflate to < 1 GiB, and submits them -- asynchronously, in
  *                    runs of consecutive batches per GPU (contiguous record blocks)
  *
- * Works for files whose BGZF blocks start on record boundaries (everything htslib writes).  When
- * the device index finds a record crossing blocks (PSSBAM_FEED_RAGGED) the caller re-runs the file
- * through the host reader, whose indexer follows the chain across blocks.
+ * Records may cross BGZF blocks (htsjdk writers) and batches: the device stitches the record chain from
+ * per-block pieces and carries the partial record at a super-batch's end into the next one.  Only
+ * when the pieces do not link up (PSSBAM_FEED_RAGGED: a false start, a record above 16 MiB) does the
+ * caller re-run the file through the host reader, whose indexer walks the chain serially.
  */
 #include "device_feed.h"
 
@@ -315,6 +316,7 @@ int run_device_feed(pssbam_engine *const *eng, int n_gpus, const char *path, siz
     }
     if (fs->flags & (PSSBAM_FEED_RAGGED | PSSBAM_FEED_BAD_RECORD)) fs->fallback = 1; /* the host reader follows records across blocks (and words the diagnosis) */
     else if (fs->flags & PSSBAM_FEED_BAD_BLOCK) { fprintf(stderr, "Error: %s: BGZF inflate / CRC check failed\n", path); goto done; }
+    else if (fs->flags & PSSBAM_FEED_TRUNCATED) { fprintf(stderr, "Error: %s: truncated alignment record at end of file\n", path); goto done; }
     if (verbose)
         fprintf(stderr, "[pssbam] device feed: %llu submits, %.2f GB compressed over PCIe, %.2f GB inflated on the device in %.3f s "
                         "of kernel time (%.1f GB/s), %d loader threads, %d staging slots of %zu MiB%s\n",

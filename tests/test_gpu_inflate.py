@@ -207,35 +207,73 @@ def test_feed_compressed_bam_to_tables(pkg, tmp_path, seed, with_rg):
                 assert st_g == st_w, (mode, got.stats, want.stats)
 
 
-def test_feed_flags_ragged_layout_and_damage(pkg, tmp_path):
-    """records crossing BGZF blocks raise PSSBAM_FEED_RAGGED (the caller then uses the host reader); a
-    damaged block raises PSSBAM_FEED_BAD_BLOCK"""
-    contigs, refs, recs = tl.fuzz_dataset(31, 3000)
-    bam = tmp_path / "ragged.bam"
-    tl.write_bam(bam, refs, recs, level=1, rng=np.random.default_rng(3), block=5000)
-    raw = bam.read_bytes()
-    eng = pkg.Engine(pss=dict(region_len=15))
+def _feed_tables(pkg, contigs, refs, raw_bgzf, hb, pss, kmer=None, max_batch=1 << 30):
+    eng = pkg.Engine(pss=pss, kmer=kmer)
     eng.set_genome_arrays(tl.loaded_contigs(contigs))
     eng.set_references([n for n, _ in refs])
-    eng.submit_bgzf(np.frombuffer(raw, dtype=np.uint8), header_bytes=_bam_header_bytes(raw))
-    assert eng.feed_status()["flags"] & 2
+    eng.submit_bgzf(np.frombuffer(raw_bgzf, dtype=np.uint8), header_bytes=hb, max_batch_inflated=max_batch)
+    st = eng.feed_status()
+    got = eng.finish()
     eng.close()
-    good = (GOLD / "setA.bam").read_bytes()
+    return got, st
+
+
+@pytest.mark.parametrize("block,seed", [(5000, 3), (300, 4), (70, 5), (0xFF00, 6)])
+def test_feed_records_crossing_blocks(pkg, tmp_path, monkeypatch, block, seed):
+    """htsjdk-style layouts: BGZF blocks cut regardless of records (down to 70-byte blocks, so a record
+    spans many blocks and even its length word is split).  The device stitches the chain from per-block
+    pieces; with tiny super-batches the partial record at the end of one is carried into the next.
+    Tables and status tallies must equal the host path's."""
+    contigs, refs, recs = tl.fuzz_dataset(60 + seed, 2500)
+    bam = tmp_path / "ragged.bam"
+    tl.write_bam(bam, refs, recs, level=1, rng=np.random.default_rng(seed), block=block)
+    raw = bam.read_bytes()
+    hb = _bam_header_bytes(raw)
+    rec_bytes = tl.raw_records(refs, recs)
+    pss, kmer = dict(region_len=15 if seed % 2 else 25), dict(klen=5)
+    eng = pkg.Engine(pss=pss, kmer=kmer)
+    eng.set_genome_arrays(tl.loaded_contigs(contigs))
+    eng.set_references([n for n, _ in refs])
+    eng.submit(rec_bytes)
+    want = eng.finish()
+    eng.close()
+    for super_bytes, max_batch in ((None, 1 << 30), ("1048576", 40000), ("1048576", 1 << 30)):
+        if super_bytes:
+            monkeypatch.setenv("PSSBAM_FEED_SUPER_BYTES", super_bytes)   # ~10 super-batches: tails are carried
+        else:
+            monkeypatch.delenv("PSSBAM_FEED_SUPER_BYTES", raising=False)
+        got, st = _feed_tables(pkg, contigs, refs, raw, hb, pss, kmer, max_batch)
+        assert st["flags"] == 0, (block, super_bytes, st)
+        assert np.array_equal(got.fwd, want.fwd) and np.array_equal(got.rev, want.rev), (block, super_bytes)
+        assert np.array_equal(got.k5, want.k5) and np.array_equal(got.k3, want.k3)
+        a, b = dict(got.stats), dict(want.stats)
+        a.pop("slow_path"), b.pop("slow_path")
+        assert a == b, (block, super_bytes, got.stats, want.stats)
+
+
+def test_feed_flags_damage_and_truncation(pkg, tmp_path):
+    """a damaged block raises PSSBAM_FEED_BAD_BLOCK; a stream that ends inside a record raises
+    PSSBAM_FEED_TRUNCATED"""
+    contigs, refs, recs = tl.fuzz_dataset(31, 3000)
+    bam = tmp_path / "a.bam"
+    hb = tl.write_bam_aligned(bam, refs, recs, level=1, rng=np.random.default_rng(3))
+    good = bam.read_bytes()
     bad = bytearray(good)
     bad[len(bad) // 2] ^= 0x10
-    refs2, _ = tl.read_bam(GOLD / "setA.bam")
-    eng = pkg.Engine(pss=dict(region_len=15))
-    eng.set_genome_arrays(tl.loaded_contigs(_contigs_of(GOLD / "setA.fa")))
-    eng.set_references([n for n, _ in refs2])
-    eng.submit_bgzf(np.frombuffer(bytes(bad), dtype=np.uint8), header_bytes=_bam_header_bytes(good))
-    assert eng.feed_status()["flags"] & 1
-    eng.close()
+    _, st = _feed_tables(pkg, contigs, refs, bytes(bad), hb, dict(region_len=15))
+    assert st["flags"] & 1
+    # cut the inflated stream in the middle of a record: re-block the first 60 % of it
+    data = tl.bgzf_inflate(good)
+    cut = data[:int(len(data) * 0.6)]
+    blocks = b"".join(tl.bgzf_block(cut[i:i + 0xFF00], 1) for i in range(0, len(cut), 0xFF00)) + tl.BGZF_EOF
+    _, st = _feed_tables(pkg, contigs, refs, blocks, hb, dict(region_len=15))
+    assert st["flags"] & 8 and not st["flags"] & 1
 
 
 def test_cli_device_feed_and_fallback(pkg, oracle, tmp_path):
-    """bin/pss-bam / bin/fragkon with the inflate on the device: htslib-layout BAMs are fed compressed
-    (many small chunks and submits, two engines), a BAM whose records cross BGZF blocks falls back to
-    the host reader, PSSBAM_DEVICE_INFLATE=0 keeps the host path -- identical tables every way"""
+    """bin/pss-bam / bin/fragkon with the inflate on the device: htslib-layout BAMs and BAMs whose
+    records cross BGZF blocks are fed compressed (many small chunks and submits, two engines),
+    PSSBAM_DEVICE_INFLATE=0 keeps the host path -- identical tables every way"""
     import os
     import re
     import subprocess
@@ -273,8 +311,8 @@ def test_cli_device_feed_and_fallback(pkg, oracle, tmp_path):
                             "PSSBAM_OVERSUBSCRIBE": "1", "PSSBAM_LOADER_THREADS": "3"})
     m = re.search(r"device feed: (\d+) submits", err)
     assert m and int(m.group(1)) >= 10 and "gpus=2" in err
-    err = run_pss(ragged, {})
-    assert "falling back to the host reader" in err
+    err = run_pss(ragged, {})                                   # records cross BGZF blocks: still fed compressed
+    assert re.search(r"device feed: (\d+) submits", err) and "host reader" not in err
     err = run_pss(aligned, {"PSSBAM_DEVICE_INFLATE": "0"})
     assert "device feed" not in err
     pr = subprocess.run([str(b / "fragkon"), "-F", str(fa), "-B", str(aligned)] + ko.argv(), capture_output=True, text=True)
