@@ -311,7 +311,7 @@ int run_tally(const pssbam_config *cfg, Genome *genome, const char *aln_path, in
     }
     while (fifo_len > 0) RETIRE_OLDEST();
 #undef RETIRE_OLDEST
-    if (verbose && n_gpus > 1)
+    if (verbose && n_gpus > 1 && !fed_on_device)
         fprintf(stderr, "[pssbam] feed: %llu batches in runs of %d over %d engines, up to %d copies in flight; copy windows of "
                         "different engines overlapped for %.3f s\n", (unsigned long long)n_batches, run, n_gpus, max_inflight, overlap_s);
     t_mark = now_s();

@@ -107,7 +107,7 @@ def test_cli_on_generated_bam_vs_oracle(bins, oracle, tmp_path):
     # and small batches so that every engine gets several; same tables, both ways of summing
     for reduce in ("", "host"):
         env = {**os.environ, "PSSBAM_NGPU": "3", "PSSBAM_OVERSUBSCRIBE": "1", "PSSBAM_BATCH_BYTES": str(1 << 20),
-               "PSSBAM_REDUCE": reduce, "PSSBAM_STATS": "1"}
+               "PSSBAM_REDUCE": reduce, "PSSBAM_STATS": "1", "PSSBAM_DEVICE_INFLATE": "0"}   # the HOST reader's asynchronous feed
         pr = subprocess.run([str(bins / "pss-bam"), "-F", str(fa), "-B", str(bam), "-o", str(tmp_path / "out3")] + po.argv(),
                             capture_output=True, text=True, env=env)
         assert pr.returncode == 0, pr.stderr
@@ -129,7 +129,8 @@ def test_cli_on_generated_bam_vs_oracle(bins, oracle, tmp_path):
         assert float(m.group(4)) >= 0      # (printed with millisecond resolution: 1 MiB copies overlap for microseconds)
     # and a run length of 1 / other geometries give the same tables
     for extra in ({"PSSBAM_RUN_BATCHES": "1"}, {"PSSBAM_RUN_BATCHES": "3", "PSSBAM_SLOTS": "4"}):
-        env = {**os.environ, "PSSBAM_NGPU": "2", "PSSBAM_OVERSUBSCRIBE": "1", "PSSBAM_BATCH_BYTES": str(1 << 20), **extra}
+        env = {**os.environ, "PSSBAM_NGPU": "2", "PSSBAM_OVERSUBSCRIBE": "1", "PSSBAM_BATCH_BYTES": str(1 << 20),
+               "PSSBAM_DEVICE_INFLATE": "0", **extra}
         pr = subprocess.run([str(bins / "pss-bam"), "-F", str(fa), "-B", str(bam), "-o", str(tmp_path / "out4")] + po.argv(),
                             capture_output=True, text=True, env=env)
         assert pr.returncode == 0, pr.stderr
