@@ -244,6 +244,10 @@ int pssbam_bgzf_inflate_device(void *hip_stream, const void *d_comp, uint64_t co
 int pssbam_engine_submit_bgzf(pssbam_engine *e, const void *comp, uint64_t comp_bytes, const pssbam_bgzf_block *blocks,
                               uint32_t n_blocks, uint32_t first_record_offset, uint64_t *ticket);
 int pssbam_engine_wait_bgzf_copied(pssbam_engine *e, uint64_t ticket);
+/* The blocks submitted next do NOT continue the stream fed so far (an engine that is dealt every n-th
+ * run of a file): pending blocks are processed, a partial record left at this point raises
+ * PSSBAM_FEED_TRUNCATED, and the next blocks start a new record chain at their first byte. */
+int pssbam_engine_feed_break(pssbam_engine *e);
 #define PSSBAM_FEED_BAD_BLOCK 1u   /* a block failed inflate / ISIZE / CRC-32                         */
 #define PSSBAM_FEED_RAGGED 2u      /* the per-block record chains did not link up (or a record above 16 MiB):
                                       use the host reader for this file                               */

@@ -38,7 +38,7 @@ HIP_SYMBOLS = [
     "pssbam_reduce_counters", "pssbam_engine_genome_kmer_count", "pssbam_host_register", "pssbam_host_unregister", "pssbam_engine_timer_begin",
     "pssbam_engine_timer_end", "pssbam_engine_kernel_time", "pssbam_index_records", "pssbam_bgzf_scan",
     "pssbam_bgzf_inflate_device", "pssbam_bgzf_inflate_host", "pssbam_engine_submit_bgzf", "pssbam_engine_wait_bgzf_copied",
-    "pssbam_engine_feed_status", "pssbam_feed_reserve", "pssbam_engine_hint_records",
+    "pssbam_engine_feed_status", "pssbam_engine_feed_break", "pssbam_feed_reserve", "pssbam_engine_hint_records",
 ]
 
 
@@ -306,6 +306,10 @@ class Engine:
             skip = 0
             i = j
         return int(n)
+
+    def feed_break(self):
+        self._L.pssbam_engine_feed_break.argtypes = [C.c_void_p]
+        _chk(self._L.pssbam_engine_feed_break(self._h))
 
     def feed_status(self) -> dict:
         L = self._L

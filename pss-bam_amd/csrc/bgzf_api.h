@@ -473,6 +473,24 @@ extern "C" int pssbam_engine_submit_bgzf(pssbam_engine *e, const void *comp, uin
     return PSSBAM_OK;
 }
 
+// The blocks submitted next do not continue the stream fed so far (e.g. this engine is dealt every
+// n-th run of a file): what is pending is flushed, a partial record left at this point is an error
+// (PSSBAM_FEED_TRUNCATED -- it can never be completed), and the next blocks start a new chain at a
+// record boundary.
+extern "C" int pssbam_engine_feed_break(pssbam_engine *e) {
+    if (!e) return fail(PSSBAM_EINVAL, "null engine");
+    HIP_TRY(hipSetDevice(e->device));
+    int rc = feed_flush(e);
+    if (rc) return rc;
+    if (e->d_feed_tail) {
+        hipLaunchKernelGGL(pssbam::bgzf_chain_break, dim3(1), dim3(64), 0, e->stream, e->d_feed_tail, e->d_feed_flags);
+        HIP_TRY(hipGetLastError());
+    }
+    e->feed_fresh = true;
+    e->feed_skip = 0;
+    return PSSBAM_OK;
+}
+
 // copy completion of a submit_bgzf ticket (the caller's compressed chunk is then free)
 extern "C" int pssbam_engine_wait_bgzf_copied(pssbam_engine *e, uint64_t ticket) {
     if (!e) return fail(PSSBAM_EINVAL, "null engine");

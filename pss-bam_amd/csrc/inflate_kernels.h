@@ -734,4 +734,13 @@ __global__ void __launch_bounds__(256) bgzf_chain_carry(const uint8_t *src_out, 
     if (threadIdx.x == 0) { *next_first_start = gap - len; *tail_len_out = len; }
 }
 
+// the caller declares that the next blocks do not continue the stream fed so far: a partial record
+// left over at this point can never be completed
+__global__ void bgzf_chain_break(uint64_t *tail_len, uint32_t *flags) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        if (*tail_len) atomicOr(flags, FEED_TRUNCATED);
+        *tail_len = 0;
+    }
+}
+
 }  // namespace pssbam

@@ -217,6 +217,7 @@ int run_device_feed(pssbam_engine *const *eng, int n_gpus, const char *path, siz
     size_t pos = 0;                /* file offset of the next BGZF block */
     size_t skip = header_bytes;    /* inflated bytes still to skip in front of the first record */
     uint64_t n_submits = 0;
+    int last_g = -1;
     for (long k = 0; k < L.n_chunks; k++) {
         stage_t *s = &L.st[k % L.n_st];
         const double tw = mono_s();
@@ -272,6 +273,10 @@ int run_device_feed(pssbam_engine *const *eng, int n_gpus, const char *path, siz
                 }
                 const uint64_t end_in = bl[j - 1].in_off + bl[j - 1].in_len;
                 const int g = (int)((n_submits / (uint64_t)run) % (uint64_t)n_gpus);
+                if (n_gpus > 1 && g != last_g) { /* this engine's previous run ended elsewhere in the file: a new record chain */
+                    if (pssbam_engine_feed_break(eng[g])) { fprintf(stderr, "Error: GPU engine: %s\n", pssbam_last_error()); goto done; }
+                    last_g = g;
+                }
                 uint64_t ticket = 0;
                 const double tsub = mono_s();
                 if (pssbam_engine_submit_bgzf(eng[g], s->buf + chunk_rel + base_in, end_in - base_in, grp, (uint32_t)(j - i), (uint32_t)skip,
@@ -315,6 +320,9 @@ int run_device_feed(pssbam_engine *const *eng, int n_gpus, const char *path, siz
         fs->inflated_bytes += ib;
     }
     if (fs->flags & (PSSBAM_FEED_RAGGED | PSSBAM_FEED_BAD_RECORD)) fs->fallback = 1; /* the host reader follows records across blocks (and words the diagnosis) */
+    else if (n_gpus > 1 && (fs->flags & PSSBAM_FEED_TRUNCATED) && !(fs->flags & PSSBAM_FEED_BAD_BLOCK))
+        fs->fallback = 1; /* several engines, each fed runs of the file: a record crossing from one run into the next
+                             cannot be stitched across devices -- the host reader takes such files */
     else if (fs->flags & PSSBAM_FEED_BAD_BLOCK) { fprintf(stderr, "Error: %s: BGZF inflate / CRC check failed\n", path); goto done; }
     else if (fs->flags & PSSBAM_FEED_TRUNCATED) { fprintf(stderr, "Error: %s: truncated alignment record at end of file\n", path); goto done; }
     if (verbose)

@@ -315,6 +315,10 @@ def test_cli_device_feed_and_fallback(pkg, oracle, tmp_path):
     assert re.search(r"device feed: (\d+) submits", err) and "host reader" not in err
     err = run_pss(aligned, {"PSSBAM_DEVICE_INFLATE": "0"})
     assert "device feed" not in err
+    # two engines are dealt alternating runs of the file: a record crossing from one run into the next cannot
+    # be stitched across devices, so a file in htsjdk's layout goes to the host reader -- same tables
+    err = run_pss(ragged, {"PSSBAM_CHUNK_BYTES": str(1 << 20), "PSSBAM_NGPU": "2", "PSSBAM_OVERSUBSCRIBE": "1"})
+    assert "falling back to the host reader" in err and "gpus=2" in err
     pr = subprocess.run([str(b / "fragkon"), "-F", str(fa), "-B", str(aligned)] + ko.argv(), capture_output=True, text=True)
     assert pr.returncode == 0, pr.stderr
     g5, g3 = tl.parse_fragkon_text(pr.stdout)
