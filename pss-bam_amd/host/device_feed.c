@@ -140,7 +140,7 @@ int run_device_feed(pssbam_engine *const *eng, int n_gpus, const char *path, siz
                     device_feed_stats *fs)
 {
     loader_t L;
-    pthread_t th[16];
+    pthread_t th[32];
     int n_th = 0, rc = -1, registered = 0;
     uint8_t *stage_base = NULL;
     pssbam_bgzf_block *blocks = NULL, *grp = NULL;
@@ -160,7 +160,14 @@ int run_device_feed(pssbam_engine *const *eng, int n_gpus, const char *path, siz
     L.n_chunks = (long)((L.file_size + L.W - 1) / L.W);
     size_t out_cap = env_size("PSSBAM_FEED_BATCH_BYTES", (size_t)768 << 20); /* inflated bytes per submit */
     if (out_cap > ((size_t)1 << 30)) out_cap = (size_t)1 << 30;
-    const int max_inflight = n_gpus * run < 2 ? 2 : n_gpus * run;
+    /* several engines: a run per engine is as long as one of its super-batches (so the inflate kernel of every
+     * GPU still gets full launches; a run switch flushes what the engine has collected), while the number of
+     * copies in flight only has to cover the links' latency */
+    if (n_gpus > 1 && !getenv("PSSBAM_RUN_BATCHES")) {
+        const size_t per_super = ((size_t)10800 << 20) / out_cap;
+        if ((size_t)run < per_super) run = (int)per_super;
+    }
+    const int max_inflight = n_gpus * 2 < 2 ? 2 : n_gpus * 2;
     L.n_st = max_inflight + 8 > MAX_STAGE ? MAX_STAGE : max_inflight + 8;   /* windows being read ahead + in flight */
     if ((long)L.n_st > L.n_chunks + 1) L.n_st = (int)L.n_chunks + 1;
     const size_t slot_bytes = (L.W + OVER + 4096 + 4095) & ~(size_t)4095;
@@ -179,8 +186,8 @@ int run_device_feed(pssbam_engine *const *eng, int n_gpus, const char *path, siz
     if (!getenv("PSSBAM_NO_PIN")) registered = pssbam_host_register(stage_base, slot_bytes * (size_t)L.n_st) == 0;
     {
         long cpus = sysconf(_SC_NPROCESSORS_ONLN);
-        int want = (int)env_size("PSSBAM_LOADER_THREADS", 8);
-        if (want > 16) want = 16;
+        int want = (int)env_size("PSSBAM_LOADER_THREADS", n_gpus > 2 ? 4 * (size_t)n_gpus : 8);
+        if (want > 32) want = 32;
         if (cpus > 0 && want > cpus) want = (int)cpus;
         if ((long)want > L.n_chunks) want = (int)L.n_chunks;
         for (int t = 0; t < want; t++)

@@ -308,7 +308,7 @@ def test_cli_device_feed_and_fallback(pkg, oracle, tmp_path):
     m = re.search(r"device feed: (\d+) submits", err)
     assert m and "host reader" not in err, err[-1500:]
     err = run_pss(aligned, {"PSSBAM_CHUNK_BYTES": str(1 << 20), "PSSBAM_FEED_BATCH_BYTES": str(3 << 20), "PSSBAM_NGPU": "2",
-                            "PSSBAM_OVERSUBSCRIBE": "1", "PSSBAM_LOADER_THREADS": "3"})
+                            "PSSBAM_OVERSUBSCRIBE": "1", "PSSBAM_LOADER_THREADS": "3", "PSSBAM_RUN_BATCHES": "2"})
     m = re.search(r"device feed: (\d+) submits", err)
     assert m and int(m.group(1)) >= 10 and "gpus=2" in err
     err = run_pss(ragged, {})                                   # records cross BGZF blocks: still fed compressed
@@ -317,7 +317,8 @@ def test_cli_device_feed_and_fallback(pkg, oracle, tmp_path):
     assert "device feed" not in err
     # two engines are dealt alternating runs of the file: a record crossing from one run into the next cannot
     # be stitched across devices, so a file in htsjdk's layout goes to the host reader -- same tables
-    err = run_pss(ragged, {"PSSBAM_CHUNK_BYTES": str(1 << 20), "PSSBAM_NGPU": "2", "PSSBAM_OVERSUBSCRIBE": "1"})
+    err = run_pss(ragged, {"PSSBAM_CHUNK_BYTES": str(1 << 20), "PSSBAM_NGPU": "2", "PSSBAM_OVERSUBSCRIBE": "1",
+                           "PSSBAM_FEED_BATCH_BYTES": str(3 << 20), "PSSBAM_RUN_BATCHES": "2"})
     assert "falling back to the host reader" in err and "gpus=2" in err
     pr = subprocess.run([str(b / "fragkon"), "-F", str(fa), "-B", str(aligned)] + ko.argv(), capture_output=True, text=True)
     assert pr.returncode == 0, pr.stderr
