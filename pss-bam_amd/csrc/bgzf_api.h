@@ -97,8 +97,13 @@ extern "C" int pssbam_bgzf_inflate_device(void *hip_stream, const void *d_comp, 
         uint32_t *xpow = nullptr;
         int rc = ensure_xpow(dev, &xpow);
         if (rc) return rc;
-        const uint32_t cgrid = std::min<uint32_t>((n_blocks + 3) / 4, (uint32_t)n_cu * 8u);
-        hipLaunchKernelGGL(pssbam::bgzf_crc_kernel, dim3(cgrid), dim3(256), 0, st, (const uint8_t *)d_out, (pssbam::BgzfBlock *)d_blocks, n_blocks, xpow);
+        static bool crc_attr_set[64] = {false};
+        if (!crc_attr_set[dev & 63]) {
+            HIP_TRY(hipFuncSetAttribute((const void *)pssbam::bgzf_crc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pssbam::CRC_LDS_BYTES));
+            crc_attr_set[dev & 63] = true;
+        }
+        const uint32_t cgrid = std::min<uint32_t>((n_blocks + 15) / 16, (uint32_t)n_cu);   // one 16-wave workgroup per CU, a block per wave
+        hipLaunchKernelGGL(pssbam::bgzf_crc_kernel, dim3(cgrid), dim3(1024), pssbam::CRC_LDS_BYTES, st, (const uint8_t *)d_out, (pssbam::BgzfBlock *)d_blocks, n_blocks, xpow);
         HIP_TRY(hipGetLastError());
     }
     return PSSBAM_OK;

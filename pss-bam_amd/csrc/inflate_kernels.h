@@ -487,20 +487,24 @@ __device__ __forceinline__ uint32_t gf2_mul(uint32_t a, uint32_t b) {
 // chunk CRCs (no pre/post conditioning except the 0xFFFFFFFF start on the first data byte) are
 // moved to the end of the block by multiplying with x^(8 * bytes behind the chunk) -- powers of
 // x^(8 * 1024) from a 64-entry table -- and XORed together.
-__global__ void __launch_bounds__(256) bgzf_crc_kernel(const uint8_t *out, BgzfBlock *blocks, uint32_t n_blocks,
-                                                       const uint32_t *xpow_kib /* [64]: x^(8*1024*k) mod P */) {
-    __shared__ uint32_t tab[4][256];
-    for (uint32_t i = threadIdx.x; i < 256u; i += blockDim.x) {
-        uint32_t c = i;
-        for (int k = 0; k < 8; k++) c = (c >> 1) ^ ((c & 1u) ? CRC_POLY : 0u);
-        tab[0][i] = c;
+constexpr uint32_t CRC_REP = 32;   // copies of every table entry, one per LDS bank
+constexpr uint32_t CRC_LDS_BYTES = 4u * 256u * CRC_REP * 4u;   // 128 KiB: one workgroup of 16 waves per CU
+__global__ void __launch_bounds__(1024) bgzf_crc_kernel(const uint8_t *out, BgzfBlock *blocks, uint32_t n_blocks,
+                                                        const uint32_t *xpow_kib /* [64]: x^(8*1024*k) mod P */) {
+    // slicing-by-4 tables, every entry replicated 32 times side by side: lane l reads copy l % 32, i.e. ALWAYS
+    // bank l % 32 -- the random table indices of a wave's 64 lanes no longer collide (a single copy of the
+    // tables had 67 % of the LDS cycles lost to bank conflicts: profiles/r02_inflate_prof_100M_5waves.txt)
+    extern __shared__ uint32_t crc_tab[];   // [4][256][CRC_REP]
+    for (uint32_t i = threadIdx.x; i < 4u * 256u * CRC_REP; i += blockDim.x) {
+        const uint32_t t = i / (256u * CRC_REP), v = (i / CRC_REP) & 255u;
+        uint32_t c = v;   // CRC register after byte v followed by t zero bytes
+        for (uint32_t k = 0; k < 8u * (t + 1u); k++) c = (c >> 1) ^ ((c & 1u) ? CRC_POLY : 0u);
+        crc_tab[i] = c;
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < 256u; i += blockDim.x) {
-        uint32_t c = tab[0][i];
-        for (int s = 1; s < 4; s++) { c = tab[0][c & 0xFFu] ^ (c >> 8); tab[s][i] = c; }
-    }
-    __syncthreads();
+    const uint32_t rep = threadIdx.x & (CRC_REP - 1u);
+    const uint32_t *tab0 = crc_tab + rep, *tab1 = tab0 + 256u * CRC_REP, *tab2 = tab1 + 256u * CRC_REP, *tab3 = tab2 + 256u * CRC_REP;
+#define TAB(t, v) (t)[(v) * CRC_REP]
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
     for (uint32_t bi = blockIdx.x * waves + wave; bi < n_blocks; bi += gridDim.x * waves) {
         const BgzfBlock b = blocks[bi];
@@ -514,17 +518,17 @@ __global__ void __launch_bounds__(256) bgzf_crc_kernel(const uint8_t *out, BgzfB
         // 16 bytes per load: the lanes of a wave read 1 KiB apart (one cache line each), so a dword at a
         // time would fetch every line 32 times over
         uint32_t i = s;
-        for (; i < e && ((uintptr_t)(p + i) & 15u); i++) crc = tab[0][(crc ^ p[i]) & 0xFFu] ^ (crc >> 8);
+        for (; i < e && ((uintptr_t)(p + i) & 15u); i++) crc = TAB(tab0, (crc ^ p[i]) & 0xFFu) ^ (crc >> 8);
         for (; i + 16u <= e; i += 16u) {
             const uint4 q = *(const uint4 *)(p + i);
             const uint32_t d[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const uint32_t w = d[k] ^ crc;
-                crc = tab[3][w & 0xFFu] ^ tab[2][(w >> 8) & 0xFFu] ^ tab[1][(w >> 16) & 0xFFu] ^ tab[0][w >> 24];
+                crc = TAB(tab3, w & 0xFFu) ^ TAB(tab2, (w >> 8) & 0xFFu) ^ TAB(tab1, (w >> 16) & 0xFFu) ^ TAB(tab0, w >> 24);
             }
         }
-        for (; i < e; i++) crc = tab[0][(crc ^ p[i]) & 0xFFu] ^ (crc >> 8);
+        for (; i < e; i++) crc = TAB(tab0, (crc ^ p[i]) & 0xFFu) ^ (crc >> 8);
         if (behind && e > 0u) crc = gf2_mul(crc, xpow_kib[63u - lane]);
         if (e == 0u) crc = 0u;
         for (int o = 32; o >= 1; o >>= 1) crc ^= (uint32_t)__shfl_xor((int)crc, o);
@@ -533,6 +537,7 @@ __global__ void __launch_bounds__(256) bgzf_crc_kernel(const uint8_t *out, BgzfB
             if (final_crc != b.crc) blocks[bi].status = INF_BAD_CRC;
         }
     }
+#undef TAB
 }
 
 
