@@ -332,3 +332,38 @@ def test_cli_device_feed_and_fallback(pkg, oracle, tmp_path):
     pr = subprocess.run([str(b / "pss-bam"), "-F", str(fa), "-B", str(bad), "-o", str(tmp_path / "x")] + po.argv(),
                         capture_output=True, text=True)
     assert pr.returncode != 0 and "Error" in pr.stderr
+
+
+def test_cli_device_feed_edge_files(pkg, tmp_path):
+    """header-only BAM -> all-zero tables; a BAM cut in the middle of a BGZF block, or in the middle of a
+    record, -> a diagnosed failure (not a table)"""
+    import os
+    import subprocess
+    contigs, refs, recs = tl.fuzz_dataset(77, 1500)
+    fa = tmp_path / "g.fa"
+    tl.write_fasta(fa, contigs)
+    b = pkg.PKG_DIR / "bin"
+
+    def run(bam, prefix):
+        return subprocess.run([str(b / "pss-bam"), "-F", str(fa), "-B", str(bam), "-o", str(tmp_path / prefix), "-r", "10"],
+                              capture_output=True, text=True, env={**os.environ, "PSSBAM_STATS": "1"})
+
+    empty = tmp_path / "empty.bam"
+    tl.write_bam_aligned(empty, refs, [], level=6)
+    pr = run(empty, "e")
+    assert pr.returncode == 0, pr.stderr
+    f, r = tl.parse_counts_text((tmp_path / "e.pss.counts.txt").read_text())
+    assert f.sum() == 0 and r.sum() == 0 and "[pssbam] records=0" in pr.stderr
+    full = tmp_path / "full.bam"
+    tl.write_bam_aligned(full, refs, recs, level=6)
+    raw = full.read_bytes()
+    cut_block = tmp_path / "cut_block.bam"
+    cut_block.write_bytes(raw[:len(raw) // 2])                      # ends inside a BGZF block
+    pr = run(cut_block, "c1")
+    assert pr.returncode != 0 and "Error" in pr.stderr
+    data = tl.bgzf_inflate(raw)
+    part = data[:int(len(data) * 0.7)]                               # ends inside an alignment record, blocks intact
+    cut_rec = tmp_path / "cut_rec.bam"
+    cut_rec.write_bytes(b"".join(tl.bgzf_block(part[i:i + 0xFF00], 6) for i in range(0, len(part), 0xFF00)) + tl.BGZF_EOF)
+    pr = run(cut_rec, "c2")
+    assert pr.returncode != 0 and "truncated" in pr.stderr.lower(), pr.stderr[-1500:]
