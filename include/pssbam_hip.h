@@ -229,7 +229,9 @@ int64_t pssbam_bgzf_scan(const void *bytes, uint64_t nbytes, pssbam_bgzf_block *
 
 /* Inflates n_blocks blocks on the current device, asynchronously on hip_stream: d_comp (4-byte
  * aligned, readable 4 bytes past comp_bytes) -> d_out at each block's out_off; d_blocks[i].status
- * tells how block i went (check_crc != 0 adds the ISIZE/CRC-32 kernel). */
+ * tells how block i went (check_crc != 0 adds the ISIZE/CRC-32 kernel).  d_out must hold
+ * out_off + isize bytes for every block: the table is the caller's, and only its in_off / in_len /
+ * isize are checked on the device (a block that fails them gets status 1 and is not touched). */
 int pssbam_bgzf_inflate_device(void *hip_stream, const void *d_comp, uint64_t comp_bytes, pssbam_bgzf_block *d_blocks,
                                uint32_t n_blocks, void *d_out, int check_crc);
 

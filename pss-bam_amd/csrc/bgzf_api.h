@@ -286,7 +286,8 @@ static int feed_flush(pssbam_engine *e) {
         s.blocks_cap = *std::min_element(c, c + 8);
     }
     const uint64_t data_end = s.out_used;   // the blocks sit contiguously in [FEED_GAP, data_end)
-    if ((rc = grow(&s.d_offs, &s.offs_cap, (size_t)(data_end / 36ull + 2ull * s.sub_first.size() + 16ull)))) return rc;
+    // (offsets: a block of isize bytes starts at most isize / 36 + 1 records, whatever its bytes are)
+    if ((rc = grow(&s.d_offs, &s.offs_cap, (size_t)(data_end / 36ull + nb + 2ull * s.sub_first.size() + 16ull)))) return rc;
     if ((rc = grow(&s.d_nrecs, &s.nrecs_cap, s.sub_first.size()))) return rc;
     if ((rc = feed_prepare(e, e->feed[e->cur_feed ^ 1]))) return rc;   // the tail goes into the other super-batch's gap
     // every chunk of this super-batch has been issued on the copy streams: the engine's stream waits for them
@@ -339,7 +340,7 @@ static int feed_flush(pssbam_engine *e) {
         hipLaunchKernelGGL(pssbam::bgzf_chain_write, dim3(igrid), dim3(256), 0, e->stream, (const uint8_t *)s.d_out, (const uint64_t *)(s.d_a + b0),
                            (const uint32_t *)(s.d_counts + b0), (const uint32_t *)(s.d_base + b0), n, base, s.d_offs + offs_at,
                            (const uint32_t *)(s.d_nrecs + k));
-        offs_at += sub_len[k] / 36ull + 2ull;
+        offs_at += sub_len[k] / 36ull + n + 2ull;
     }
     // the partial record at the end moves in front of the next super-batch's data
     {
@@ -353,7 +354,7 @@ static int feed_flush(pssbam_engine *e) {
     e->inflated_bytes += data_end - FEED_GAP;
     for (size_t k = 0; k < s.sub_first.size(); k++) {
         rc = launch_tally(e, s.d_out + sub_base[k], sub_len[k], s.d_offs + sub_offs[k],
-                          (uint32_t)std::min<uint64_t>(sub_len[k] / 36ull + 2ull, 0xFFFFFFF0ull), nullptr, 0, s.d_nrecs + k,
+                          (uint32_t)std::min<uint64_t>((k + 1 < sub_offs.size() ? sub_offs[k + 1] : offs_at) - sub_offs[k], 0xFFFFFFF0ull), nullptr, 0, s.d_nrecs + k,
                           k == 0 ? FEED_GAP : 0ull);
         if (rc) return rc;
     }
@@ -419,6 +420,14 @@ extern "C" int pssbam_engine_submit_bgzf(pssbam_engine *e, const void *comp, uin
     if (out_bytes > (1ull << 30)) return fail(PSSBAM_EINVAL, "chunk inflates to %llu bytes; keep chunks at or below 1 GiB", (unsigned long long)out_bytes);
     if (blocks[0].out_off != 0) return fail(PSSBAM_EINVAL, "blocks[0].out_off must be 0");
     if (first_record_offset > blocks[0].isize) return fail(PSSBAM_EINVAL, "first_record_offset lies beyond the first block");
+    // the kernels trust this table for every address they form: check it here, once, on the host
+    for (uint32_t i = 0; i < n_blocks; i++) {
+        const pssbam_bgzf_block &b = blocks[i];
+        if (b.isize > 65536u || b.in_len > 65536u) return fail(PSSBAM_EINVAL, "blocks[%u]: a BGZF block holds at most 64 KiB (in_len %u, isize %u)", i, b.in_len, b.isize);
+        if (b.in_off > comp_bytes || b.in_len > comp_bytes - b.in_off) return fail(PSSBAM_EINVAL, "blocks[%u]: payload lies outside the %llu-byte chunk", i, (unsigned long long)comp_bytes);
+        if (i && (b.in_off < blocks[i - 1].in_off + blocks[i - 1].in_len || b.out_off != blocks[i - 1].out_off + blocks[i - 1].isize))
+            return fail(PSSBAM_EINVAL, "blocks[%u]: blocks must be in file order with contiguous out_off", i);
+    }
     if (first_record_offset && !(e->feed_fresh && e->feed[0].blocks.empty() && e->feed[1].blocks.empty()))
         return fail(PSSBAM_ESTATE, "first_record_offset only makes sense for the first blocks of a stream (after create / reset)");
     if (first_record_offset) e->feed_skip = first_record_offset;
@@ -426,7 +435,7 @@ extern "C" int pssbam_engine_submit_bgzf(pssbam_engine *e, const void *comp, uin
     HIP_TRY(hipSetDevice(e->device));
     if (!e->d_feed_flags) {
         if (getenv("PSSBAM_FEED_SUPER_BYTES")) e->feed_out_target = std::max<uint64_t>(1ull << 20, strtoull(getenv("PSSBAM_FEED_SUPER_BYTES"), nullptr, 10));
-        // the inflate kernel keeps 3 waves x 64 lanes per CU busy, a block per lane, and blocks take about the
+        // the inflate kernel keeps INF_WAVES_PER_CU waves x 64 lanes per CU busy, a block per lane, and blocks take about the
         // same time: a super-batch of a whole number of "rounds" of blocks wastes no partial round
         const uint64_t lanes = (uint64_t)e->n_cu * (uint64_t)pssbam::INF_WAVES_PER_CU * 64ull;
         const uint64_t rounds = std::max<uint64_t>(1, e->feed_out_target / (lanes * 65280ull));

@@ -10,8 +10,8 @@
 // chain inside a block, every lane owns a whole block and walks it with plain SIMT code --
 // 64 blocks per wave, the wave diverging between "literal" and "match" like any branchy kernel.
 //   * per-lane decode tables in LDS, lane-interleaved (entry i of lane l at [i][l]): canonical
-//     Huffman data only -- sorted symbols + one offset per code length (736 B per lane, 46 KiB per
-//     wave, three waves per CU);
+//     Huffman data only -- sorted symbols + one offset per code length (452 B per lane, 28.3 KiB per
+//     wave, five waves per CU);
 //   * a symbol's code length comes from 15 register thresholds (canonical codes are ordered:
 //     the length is the number of left-aligned upper bounds the next 15 stream bits reach), so
 //     decoding a symbol is ~40 VALU + two LDS reads, with no loop and no per-length divergence;
@@ -377,7 +377,7 @@ __device__ uint32_t inflate_block(const uint8_t *comp, uint64_t comp_bytes, cons
                 }
                 br.refill();
                 const int ds = huff_decode<15, false>(br, t, D_DELTA, D_SYM, 30, du);
-                if (ds < 0) return INF_BAD_DISTANCE;
+                if (ds < 0 || ds >= 30) return INF_BAD_DISTANCE;   // (>= 30: an unplaced slot of an incomplete code)
                 uint32_t dist;
                 {
                     const uint32_t d = (uint32_t)ds;
@@ -459,7 +459,9 @@ __global__ void __launch_bounds__(INF_WAVE) bgzf_inflate_kernel(const uint8_t *c
         if (i < n_blocks) {
             const BgzfBlock b = blocks[i];
             uint32_t st = INF_OK;
-            if (b.isize) st = inflate_block(comp, comp_bytes, b, out, t);
+            // (a descriptor the caller got wrong must not become a wild address)
+            if (b.isize > 65536u || b.in_off > comp_bytes || b.in_len > comp_bytes - b.in_off) st = INF_BAD_BLOCK;
+            else if (b.isize) st = inflate_block(comp, comp_bytes, b, out, t);
             blocks[i].status = st;
         }
     }

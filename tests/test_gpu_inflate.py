@@ -218,6 +218,36 @@ def _feed_tables(pkg, contigs, refs, raw_bgzf, hb, pss, kmer=None, max_batch=1 <
     return got, st
 
 
+def test_submit_bgzf_rejects_a_wrong_block_table(pkg):
+    """the kernels form addresses from the caller's table: one that lies is refused on the host"""
+    import ctypes as C
+
+    class Blk(C.Structure):
+        _fields_ = [("in_off", C.c_uint64), ("in_len", C.c_uint32), ("isize", C.c_uint32), ("out_off", C.c_uint64),
+                    ("crc", C.c_uint32), ("status", C.c_uint32)]
+    contigs = [("c1", "ACGT" * 500)]
+    eng = pkg.Engine(pss=dict(region_len=5))
+    eng.set_genome_arrays(tl.loaded_contigs(contigs))
+    eng.set_references(["c1"])
+    L = eng._L
+    L.pssbam_engine_submit_bgzf.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
+    comp = np.zeros(4096, dtype=np.uint8)
+
+    def submit(rows):
+        blocks = (Blk * len(rows))(*[Blk(*r, 0, 0) for r in rows])
+        return L.pssbam_engine_submit_bgzf(eng._h, comp.ctypes.data, comp.size, blocks, len(rows), 0, None)
+    good = [(18, 100, 500, 0), (150, 100, 500, 500)]
+    for bad in ([(18, 100, 70000, 0)],                          # ISIZE above 64 KiB
+                [(18, 70000, 500, 0)],                          # payload above 64 KiB
+                [(4000, 200, 500, 0)],                          # payload runs past the chunk
+                [(1 << 40, 10, 500, 0)],                        # payload nowhere near it
+                [good[0], (150, 100, 500, 400)],                # out_off overlaps the previous block
+                [good[0], (150, 100, 500, 600)],                # ... or leaves a hole
+                [good[0], (100, 100, 500, 500)]):               # payloads out of file order
+        assert submit(bad) == -1, bad          # PSSBAM_EINVAL
+    eng.close()
+
+
 @pytest.mark.parametrize("block,seed", [(5000, 3), (300, 4), (70, 5), (0xFF00, 6)])
 def test_feed_records_crossing_blocks(pkg, tmp_path, monkeypatch, block, seed):
     """htsjdk-style layouts: BGZF blocks cut regardless of records (down to 70-byte blocks, so a record
