@@ -61,6 +61,25 @@ constexpr int L_SYM = 0, D_SYM = 288, INF_N8 = 320;
 constexpr int INF_N32 = 9;
 constexpr uint32_t INF_LDS_BYTES = (INF_N16 * 2 + INF_N8 + INF_N32 * 4) * INF_WAVE;
 constexpr int INF_WAVES_PER_CU = 5;
+// Measured variants (tools/variant_scan.sh, profiles/r02_inflate_variants.txt): none moves the kernel by
+// more than its run-to-run noise -- it is bound by round trips to a thrashing L2, not by request counts
+// (profiles/r02_inflate_pmc_mem.txt; the per-CU address path is 30 % busy) -- so the defaults are the
+// forms that cost nothing and ask the memory system for less.
+#ifndef INF_IN16
+#define INF_IN16 1        // stream read 16 bytes per request (0: a dword per request)             +1 %
+#endif
+#ifndef INF_TAIL2
+#define INF_TAIL2 1       // tails of a copy in at most two overlapping stores (0: 4 + 2 + 1 byte pieces)  0 %
+#endif
+#ifndef INF_LITMERGE
+#define INF_LITMERGE 0    // a literal run leaves as one store (0: a byte store per literal)          -1 %
+#endif
+#ifndef INF_SHORTMATCH
+#define INF_SHORTMATCH 0  // far matches of <= 16 bytes: one 16-byte load (0: always two)             -3 %
+#endif
+#ifndef INF_PAT16
+#define INF_PAT16 1       // period 1/2/4 runs stored 16 bytes per request (0: 8)                    +1 %
+#endif
 #ifndef INF_LIT_RUN
 #define INF_LIT_RUN 4u    // literals a lane may emit before the wave turns to the pending matches (2..12 measured: 291..275 GB/s)
 #endif
@@ -90,6 +109,59 @@ struct LaneLds {  // this lane's view of the three interleaved arrays
     }
 };
 
+#if INF_IN16
+struct BitReader {
+    const uint32_t *p;     // next aligned dword group to fetch
+    const uint32_t *end;   // first dword that must not be read
+    uint64_t buf;
+    uint32_t cnt;          // valid bits in buf
+    uint32_t rc;           // dwords left in the reservoir (r0 = the next two, r1 = the two behind them)
+    uint64_t r0, r1;
+    uint4 ahead;           // the 16 bytes behind the reservoir, requested when the reservoir was filled
+    uint64_t consumed;     // bits handed out
+    uint64_t limit;        // payload bits
+
+    // The stream is read 16 bytes per request (a dword per request had every 128-byte line looked up --
+    // and, with 80 000 streams thrashing L2, often fetched -- four times as often), and the group that
+    // enters the reservoir was requested a whole reservoir EARLIER: its wait only covers memory operations
+    // older than that request (vmcnt retires in order), so a refill does not drain the stores the lane has
+    // issued since.
+    __device__ __forceinline__ void fetch() {
+        if (p + 4 <= end) __builtin_memcpy(&ahead, p, 16);
+        else {
+            ahead.x = p < end ? p[0] : 0u;
+            ahead.y = p + 1 < end ? p[1] : 0u;
+            ahead.z = p + 2 < end ? p[2] : 0u;
+            ahead.w = p + 3 < end ? p[3] : 0u;
+        }
+        p += 4;
+    }
+    __device__ __forceinline__ void init() { buf = 0; cnt = 0; rc = 0; r0 = r1 = 0; consumed = 0; }
+    __device__ __forceinline__ void refill() {
+        if (cnt <= 32u) {
+            if (rc == 0u) {
+                r0 = (uint64_t)ahead.x | ((uint64_t)ahead.y << 32);
+                r1 = (uint64_t)ahead.z | ((uint64_t)ahead.w << 32);
+                rc = 4u;
+                fetch();
+            }
+            buf |= (r0 & 0xFFFFFFFFull) << cnt;
+            cnt += 32u;
+            r0 = (r0 >> 32) | (r1 << 32);
+            r1 >>= 32;
+            rc--;
+        }
+    }
+    __device__ __forceinline__ uint32_t peek15() const { return __brev((uint32_t)buf) >> 17; }  // first-read bit = MSB
+    __device__ __forceinline__ void drop(uint32_t n) { buf >>= n; cnt -= n; consumed += n; }
+    __device__ __forceinline__ uint32_t take(uint32_t n) {  // n <= 16, caller has refilled
+        const uint32_t v = (uint32_t)buf & ((1u << n) - 1u);
+        drop(n);
+        return v;
+    }
+    __device__ __forceinline__ bool overrun() const { return consumed > limit; }
+};
+#else
 struct BitReader {
     const uint32_t *p;     // next aligned dword to fetch
     const uint32_t *end;   // first dword that must not be read
@@ -106,6 +178,7 @@ struct BitReader {
         ahead = p < end ? *p : 0u;
         p++;
     }
+    __device__ __forceinline__ void init() { buf = 0; cnt = 0; consumed = 0; }
     __device__ __forceinline__ void refill() {
         if (cnt <= 32u) {
             buf |= (uint64_t)ahead << cnt;
@@ -122,6 +195,7 @@ struct BitReader {
     }
     __device__ __forceinline__ bool overrun() const { return consumed > limit; }
 };
+#endif
 
 // Canonical Huffman: builds upper[] (registers) and delta[] (LDS) from the per-length counts in
 // LDS at cnt_at (which it turns into the next-free-slot table offs[]).  false = over-subscribed.
@@ -175,11 +249,40 @@ __device__ __forceinline__ uint4 load_u128(const uint8_t *p) {
     return v;
 }
 __device__ __forceinline__ void store_u128(uint8_t *p, uint4 v) { __builtin_memcpy(p, &v, 16); }
-// the low n (< 8) bytes of v, without a loop and without loads
+// The low n (<= 8) bytes of v in at most TWO store requests: a head piece and a tail piece of the same
+// power-of-two width that overlap in the middle (the memory system here is paid per request).
 __device__ __forceinline__ void store_tail(uint8_t *p, uint64_t v, uint32_t n) {
+#if !INF_TAIL2
+    if (n & 8u) { store_u64(p, v); return; }
     if (n & 4u) { const uint32_t w = (uint32_t)v; __builtin_memcpy(p, &w, 4); p += 4; v >>= 32; }
     if (n & 2u) { const uint16_t h = (uint16_t)v; __builtin_memcpy(p, &h, 2); p += 2; v >>= 16; }
     if (n & 1u) *p = (uint8_t)v;
+    return;
+#endif
+    if (n >= 8u) store_u64(p, v);
+    else if (n >= 4u) {
+        const uint32_t a = (uint32_t)v, b = (uint32_t)(v >> (8u * (n - 4u)));
+        __builtin_memcpy(p, &a, 4);
+        __builtin_memcpy(p + n - 4u, &b, 4);
+    } else if (n >= 2u) {
+        const uint16_t a = (uint16_t)v, b = (uint16_t)(v >> (8u * (n - 2u)));
+        __builtin_memcpy(p, &a, 2);
+        __builtin_memcpy(p + n - 2u, &b, 2);
+    } else if (n) *p = (uint8_t)v;
+}
+// the low n (<= 16) bytes of (lo, hi), likewise
+__device__ __forceinline__ void store_tail16(uint8_t *p, uint64_t lo, uint64_t hi, uint32_t n) {
+    if (n >= 16u) { uint4 q; q.x = (uint32_t)lo; q.y = (uint32_t)(lo >> 32); q.z = (uint32_t)hi; q.w = (uint32_t)(hi >> 32); store_u128(p, q); }
+    else if (n > 8u) {
+#if !INF_TAIL2
+        store_u64(p, lo);
+        store_tail(p + 8, hi, n - 8u);
+        return;
+#endif
+        const uint32_t sh = 8u * (n - 8u);            // 8..56
+        store_u64(p, lo);
+        store_u64(p + n - 8u, (lo >> sh) | (hi << (64u - sh)));
+    } else store_tail(p, lo, n);
 }
 
 // One BGZF block by one lane.  Returns INF_*.
@@ -191,9 +294,7 @@ __device__ uint32_t inflate_block(const uint8_t *comp, uint64_t comp_bytes, cons
         const uint64_t a = b.in_off;
         br.p = (const uint32_t *)(comp + (a & ~3ull));
         br.end = (const uint32_t *)(comp + ((comp_bytes + 3ull) & ~3ull));
-        br.buf = 0;
-        br.cnt = 0;
-        br.consumed = 0;
+        br.init();
         br.limit = (uint64_t)b.in_len * 8ull;
         br.fetch();
         br.refill();
@@ -352,13 +453,26 @@ __device__ uint32_t inflate_block(const uint8_t *comp, uint64_t comp_bytes, cons
                 // per (literal run + match), not per token.
                 int sym;
                 uint32_t run = 0;
+                uint64_t lits = 0;   // INF_LITMERGE: the run's bytes, stored in one go (at most two requests)
+                (void)lits;
                 for (;;) {
                     br.refill();
                     sym = huff_decode<15, true>(br, t, L_DELTA, L_SYM, 288, lu);
                     if (sym < 0 || sym >= 256) break;
-                    if (pos >= isize) return INF_OVERRUN;
-                    out[pos++] = (uint8_t)sym;
+#if INF_LITMERGE
+                    lits |= (uint64_t)(uint32_t)sym << (8u * run);
+#else
+                    if (pos + run >= isize) return INF_OVERRUN;
+                    out[pos + run] = (uint8_t)sym;
+#endif
                     if (++run == INF_LIT_RUN) { sym = 512; break; }   // budget used up: give the matches their turn
+                }
+                if (run) {
+                    if (run > isize - pos) return INF_OVERRUN;
+#if INF_LITMERGE
+                    store_tail(out + pos, lits, run);
+#endif
+                    pos += run;
                 }
                 if (sym < 0) return INF_BAD_SYMBOL;
                 if (sym == 512) continue;
@@ -394,30 +508,35 @@ __device__ uint32_t inflate_block(const uint8_t *comp, uint64_t comp_bytes, cons
                 // (every path below issues its loads first and its stores last: a store is never waited
                 //  for, a load is waited for once; the over-reads stay inside the output buffer's slack)
                 if (dist >= 64u) {
-                    // far matches (the usual case in a BAM: the previous record): 32 bytes per step, and the
-                    // loads of step i+1 are issued BEFORE the stores of step i (they cannot overlap them:
-                    // src + 64 <= dst) -- the wait for a load then does not include the younger stores
+                    // far matches (the usual case in a BAM: the previous record)
                     const uint8_t *src = dst - dist;
-                    uint4 a = load_u128(src), b = load_u128(src + 16);
-                    while (len >= 64u) {
-                        const uint4 na = load_u128(src + 32), nb = load_u128(src + 48);
-                        store_u128(dst, a);
-                        store_u128(dst + 16, b);
-                        a = na; b = nb;
-                        dst += 32; src += 32; len -= 32u;
+                    if (INF_SHORTMATCH && len <= 16u) {
+                        // most matches are short: one request in, at most two out
+                        const uint4 a = load_u128(src);
+                        store_tail16(dst, (uint64_t)a.x | ((uint64_t)a.y << 32), (uint64_t)a.z | ((uint64_t)a.w << 32), len);
+                    } else {
+                        // 32 bytes per step, and the loads of step i+1 are issued BEFORE the stores of step i (they
+                        // cannot overlap them: src + 64 <= dst) -- the wait for a load then does not include the
+                        // younger stores
+                        uint4 a = load_u128(src), b = load_u128(src + 16);
+                        while (len >= 64u) {
+                            const uint4 na = load_u128(src + 32), nb = load_u128(src + 48);
+                            store_u128(dst, a);
+                            store_u128(dst + 16, b);
+                            a = na; b = nb;
+                            dst += 32; src += 32; len -= 32u;
+                        }
+                        if (len > 32u) {
+                            const uint4 na = load_u128(src + 32), nb = load_u128(src + 48);   // (src + 64 <= dst)
+                            store_u128(dst, a);
+                            store_u128(dst + 16, b);
+                            a = na; b = nb;
+                            dst += 32; src += 32; len -= 32u;
+                        }
+                        // 1..32 bytes left, all of them in (a, b)
+                        if (len >= 16u) { store_u128(dst, a); dst += 16; len -= 16u; a = b; }
+                        store_tail16(dst, (uint64_t)a.x | ((uint64_t)a.y << 32), (uint64_t)a.z | ((uint64_t)a.w << 32), len);
                     }
-                    if (len >= 32u) {
-                        const uint4 na = load_u128(src + 32), nb = load_u128(src + 48);   // (src + 64 <= dst)
-                        store_u128(dst, a);
-                        store_u128(dst + 16, b);
-                        a = na; b = nb;
-                        dst += 32; src += 32; len -= 32u;
-                    }
-                    // 0..31 bytes left, all of them in (a, b)
-                    if (len & 16u) { store_u128(dst, a); dst += 16; a = b; }
-                    uint64_t t = (uint64_t)a.x | ((uint64_t)a.y << 32);
-                    if (len & 8u) { store_u64(dst, t); dst += 8; t = (uint64_t)a.z | ((uint64_t)a.w << 32); }
-                    store_tail(dst, t, len & 7u);
                 } else if (dist >= 8u) {
                     const uint8_t *src = dst - dist;
                     while (len >= 8u) { store_u64(dst, load_u64(src)); dst += 8; src += 8; len -= 8u; }
@@ -432,9 +551,18 @@ __device__ uint32_t inflate_block(const uint8_t *comp, uint64_t comp_bytes, cons
                     }
                     pat &= dist >= 8u ? ~0ull : (1ull << (8u * dist)) - 1ull;
                     for (uint32_t w = dist; w < 8u; w <<= 1) pat |= pat << (8u * w);
-                    const uint32_t step = (8u / dist) * dist;   // whole periods per 8-byte store
-                    while (len >= 8u) { store_u64(dst, pat); dst += step; len -= step; }
-                    store_tail(dst, pat, len);
+                    if (INF_PAT16 && (8u % dist) == 0u) {
+                        // period 1, 2 or 4 (the QUAL runs): the pattern repeats every 8 bytes, 16 per request
+                        uint4 q;
+                        q.x = q.z = (uint32_t)pat;
+                        q.y = q.w = (uint32_t)(pat >> 32);
+                        while (len >= 16u) { store_u128(dst, q); dst += 16; len -= 16u; }
+                        store_tail16(dst, pat, pat, len);
+                    } else {
+                        const uint32_t step = (8u / dist) * dist;   // whole periods per 8-byte store
+                        while (len >= 8u) { store_u64(dst, pat); dst += step; len -= step; }
+                        store_tail(dst, pat, len);
+                    }
                 }
             }
             if (br.overrun()) return INF_TRUNCATED;

@@ -1,9 +1,13 @@
-# tools/variant_scan.sh -- GPU-box helper: inflate throughput of pre-built variants of libpssbam_hip.so (pss-bam_amd/variants/lib_*.so)
+# tools/variant_scan.sh -- GPU-box helper: inflate throughput of pre-built variants of libpssbam_hip.so
+# (pss-bam_amd/variants/lib_*.so, built with -DINF_...=0/1, see csrc/inflate_kernels.h); results -> gpurun_out/variant_scan.txt
+OUT=gpurun_out/variant_scan.txt
+mkdir -p gpurun_out; : > $OUT
 cp pss-bam_amd/libpssbam_hip.so /tmp/lib_orig.so
 for v in pss-bam_amd/variants/lib_*.so; do
   cp $v pss-bam_amd/libpssbam_hip.so
-  for lvl in 1 6; do
-    python3 tools/inflate_bench.py --reads ${VAR_READS:-60000000} --level $lvl --no-output --no-crc 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('$v level $lvl: %.1f GB/s, %.1f ms' % (d['device_GBps_inflated'], d['device_kernel_ms']))"
+  for lvl in ${VAR_LEVELS:-1 6}; do
+    python3 tools/inflate_bench.py --reads ${VAR_READS:-60000000} --level $lvl --no-output --no-crc 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('$v level $lvl: %.1f GB/s, %.2f ms' % (d['device_GBps_inflated'], d['device_kernel_ms']))" >> $OUT
+    tail -1 $OUT
   done
 done
 cp /tmp/lib_orig.so pss-bam_amd/libpssbam_hip.so
