@@ -488,9 +488,13 @@ def e2e_leg(pkg, synth, cd, region_len, n_reads, resident_reads, resident_counte
 
         # the same command with the inflate kept on the host threads (round 1's feed), for comparison
         pr_h, wall_h = run_cli({"PSSBAM_DEVICE_INFLATE": "0"}, "out_host")
-        pr, wall = run_cli({}, "out")
-        if pr.returncode != 0:
-            return {"error": pr.stderr[-1500:]}
+        # three runs of the command as a user would type it; the MEDIAN one is reported (its stages too):
+        # the feed's share of the wall clock moves with what the box's other tenants do to the host side
+        runs = sorted((run_cli({}, "out") for _ in range(3)), key=lambda r: r[1])
+        for r in runs:
+            if r[0].returncode != 0:
+                return {"error": r[0].stderr[-1500:]}
+        pr, wall = runs[1]
         grab = lambda pat: (lambda mm: mm.group(1) if mm else None)(re.search(pat, pr.stderr))
         tally_s = float(grab(r"total_s=([\d.]+)") or 0)
         stages = {}
@@ -511,11 +515,13 @@ def e2e_leg(pkg, synth, cd, region_len, n_reads, resident_reads, resident_counte
             "command": "bin/pss-bam -F ref.fa -B reads.bam -o out -r %d" % region_len,
             "reads": n_reads, "bam_bytes": bam.stat().st_size, "fasta_bytes": fa.stat().st_size,
             "deflate_level": 1, "block_layout": "htslib", "host_cpus_effective": effective_cpus(),
-            "wall_s": wall, "reads_per_s": n_reads / wall,
+            "wall_s": wall, "reads_per_s": n_reads / wall, "wall_s_runs": [r[1] for r in runs], "wall_s_is": "median of 3 runs",
             "tally_phase_s": tally_s, "reads_per_s_tally_phase": n_reads / tally_s if tally_s else None,
             "fasta_load_s": stages.get("fasta load"), "stages_s": stages,
             "feed": "device inflate" if "device feed:" in pr.stderr and "falling back" not in pr.stderr else "host inflate",
             "device_feed": grab(r"device feed: (.*)\n"),
+            "feed_thread": grab(r"device feed, this thread: (.*)\n"),
+            "engine_feed": grab(r"engine feed: (.*)\n"),
             "host_inflate_run": ({"wall_s": wall_h, "reads_per_s": n_reads / wall_h,
                                   "tables_identical": bool(all(np.array_equal(a, b) for a, b in zip(tl.parse_counts_text((tmp / "out_host.pss.counts.txt").read_text()), tl.parse_counts_text((tmp / "out.pss.counts.txt").read_text()))))}
                                  if pr_h.returncode == 0 else {"error": pr_h.stderr[-500:]}),
