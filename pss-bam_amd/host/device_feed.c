@@ -136,28 +136,135 @@ int device_feed_enabled(void)
     return v ? atoi(v) != 0 : 1;
 }
 
+/* a loader with its staging slots and threads: opened by run_device_feed, or ahead of it by
+ * device_feed_prefetch (the first windows are then in the slots when the engines are ready) */
+typedef struct feed_loader {
+    loader_t L;
+    pthread_t th[32];
+    int n_th;
+    uint8_t *stage_base;
+    size_t stage_bytes;
+    int registered, max_inflight;
+    char path[4096];
+} feed_loader;
+
+static void loader_close(feed_loader *F)
+{
+    if (!F) return;
+    pthread_mutex_lock(&F->L.mu);
+    F->L.stop = 1;
+    pthread_cond_broadcast(&F->L.cv);
+    pthread_mutex_unlock(&F->L.mu);
+    for (int t = 0; t < F->n_th; t++) pthread_join(F->th[t], NULL);
+    if (F->registered) pssbam_host_unregister(F->stage_base);
+    for (int i = 0; i < F->L.n_st; i++) free(F->L.st[i].pre);
+    free(F->stage_base);
+    if (F->L.fd >= 0) close(F->L.fd);
+    pthread_mutex_destroy(&F->L.mu);
+    pthread_cond_destroy(&F->L.cv);
+    free(F);
+}
+
+/* NULL: not a regular file (*not_regular = 1: pipes and the like, the host reader copes) or out of memory */
+static feed_loader *loader_open(const char *path, int n_gpus, int *not_regular)
+{
+    *not_regular = 0;
+    if (strlen(path) >= sizeof ((feed_loader *)0)->path) return NULL;
+    feed_loader *F = (feed_loader *)calloc(1, sizeof *F);
+    if (!F) return NULL;
+    loader_t *L = &F->L;
+    strcpy(F->path, path);
+    struct stat sb;
+    L->fd = open(path, O_RDONLY);
+    if (L->fd < 0 || fstat(L->fd, &sb) != 0 || !S_ISREG(sb.st_mode) || sb.st_size <= 0) {
+        if (L->fd >= 0) close(L->fd);
+        free(F);
+        *not_regular = 1;
+        return NULL;
+    }
+    L->file_size = (size_t)sb.st_size;
+    L->W = env_size("PSSBAM_CHUNK_BYTES", (size_t)32 << 20);
+    if (L->W < ((size_t)1 << 20)) L->W = (size_t)1 << 20;
+    L->W &= ~(size_t)4095;
+    L->n_chunks = (long)((L->file_size + L->W - 1) / L->W);
+    F->max_inflight = n_gpus * 2 < 2 ? 2 : n_gpus * 2;
+    L->n_st = F->max_inflight + 8 > MAX_STAGE ? MAX_STAGE : F->max_inflight + 8;   /* windows being read ahead + in flight */
+    if ((long)L->n_st > L->n_chunks + 1) L->n_st = (int)L->n_chunks + 1;
+    const size_t slot_bytes = (L->W + OVER + 4096 + 4095) & ~(size_t)4095;
+    pthread_mutex_init(&L->mu, NULL);
+    pthread_cond_init(&L->cv, NULL);
+    F->stage_bytes = slot_bytes * (size_t)L->n_st;
+    if (posix_memalign((void **)&F->stage_base, 4096, F->stage_bytes) != 0) {
+        F->stage_base = NULL;
+        loader_close(F);
+        return NULL;
+    }
+    for (int i = 0; i < L->n_st; i++) {
+        L->st[i].buf = F->stage_base + (size_t)i * slot_bytes;
+        L->st[i].free_for = i;
+        L->st[i].loaded = -1;
+        L->st[i].pre = (pssbam_bgzf_block *)malloc(sizeof(pssbam_bgzf_block) * BLOCKS_PER_SCAN); /* NULL: no pre-scan, that is all */
+    }
+    long cpus = sysconf(_SC_NPROCESSORS_ONLN);
+    int want = (int)env_size("PSSBAM_LOADER_THREADS", n_gpus > 2 ? 4 * (size_t)n_gpus : 8);
+    if (want > 32) want = 32;
+    if (cpus > 0 && want > cpus) want = (int)cpus;
+    if ((long)want > L->n_chunks) want = (int)L->n_chunks;
+    for (int t = 0; t < want; t++)
+        if (pthread_create(&F->th[F->n_th], NULL, loader_main, L) == 0) F->n_th++;
+    if (!F->n_th) {
+        loader_close(F);
+        return NULL;
+    }
+    return F;
+}
+
+static void loader_pin(feed_loader *F)
+{
+    if (F && !F->registered && !getenv("PSSBAM_NO_PIN")) F->registered = pssbam_host_register(F->stage_base, F->stage_bytes) == 0;
+}
+
+/* ---- start-up overlap: the front end opens the loader while the FASTA is still being parsed ---- */
+static feed_loader *g_pre = NULL;
+
+void device_feed_prefetch(const char *path)
+{
+    const char *ng = getenv("PSSBAM_NGPU");
+    if (g_pre || !device_feed_enabled() || (ng && atoi(ng) > 1)) return;   /* (slot count depends on the engines: one GPU only) */
+    int not_regular;
+    g_pre = loader_open(path, 1, &not_regular);
+}
+
+void device_feed_prefetch_pin(void) { loader_pin(g_pre); }   /* needs the HIP runtime: called by the warm-up thread */
+
+void device_feed_prefetch_cancel(void)
+{
+    loader_close(g_pre);
+    g_pre = NULL;
+}
+
 int run_device_feed(pssbam_engine *const *eng, int n_gpus, const char *path, size_t header_bytes, int run, int verbose,
                     device_feed_stats *fs)
 {
-    loader_t L;
-    pthread_t th[32];
-    int n_th = 0, rc = -1, registered = 0;
-    uint8_t *stage_base = NULL;
+    int rc = -1;
     pssbam_bgzf_block *blocks = NULL, *grp = NULL;
-    memset(&L, 0, sizeof L);
+    feed_loader *F = NULL;
     memset(fs, 0, sizeof *fs);
-    struct stat sb;
-    L.fd = open(path, O_RDONLY);
-    if (L.fd < 0 || fstat(L.fd, &sb) != 0 || !S_ISREG(sb.st_mode) || sb.st_size <= 0) {
-        if (L.fd >= 0) close(L.fd);
-        fs->fallback = 1; /* pipes and the like: the host reader copes */
-        return 0;
+    if (g_pre && n_gpus == 1 && strcmp(g_pre->path, path) == 0) {
+        F = g_pre;
+        g_pre = NULL;
+    } else {
+        int not_regular = 0;
+        device_feed_prefetch_cancel();
+        F = loader_open(path, n_gpus, &not_regular);
+        if (!F) {
+            if (not_regular) { fs->fallback = 1; return 0; }
+            fprintf(stderr, "Error: %s: cannot set up the device feed (memory / threads)\n", path);
+            return -1;
+        }
     }
-    L.file_size = (size_t)sb.st_size;
-    L.W = env_size("PSSBAM_CHUNK_BYTES", (size_t)32 << 20);
-    if (L.W < ((size_t)1 << 20)) L.W = (size_t)1 << 20;
-    L.W &= ~(size_t)4095;
-    L.n_chunks = (long)((L.file_size + L.W - 1) / L.W);
+#define L (F->L)
+    const int n_th = F->n_th, max_inflight = F->max_inflight;
     size_t out_cap = env_size("PSSBAM_FEED_BATCH_BYTES", (size_t)768 << 20); /* inflated bytes per submit */
     if (out_cap > ((size_t)1 << 30)) out_cap = (size_t)1 << 30;
     /* several engines: a run per engine is as long as one of its super-batches (so the inflate kernel of every
@@ -167,33 +274,10 @@ int run_device_feed(pssbam_engine *const *eng, int n_gpus, const char *path, siz
         const size_t per_super = ((size_t)10800 << 20) / out_cap;
         if ((size_t)run < per_super) run = (int)per_super;
     }
-    const int max_inflight = n_gpus * 2 < 2 ? 2 : n_gpus * 2;
-    L.n_st = max_inflight + 8 > MAX_STAGE ? MAX_STAGE : max_inflight + 8;   /* windows being read ahead + in flight */
-    if ((long)L.n_st > L.n_chunks + 1) L.n_st = (int)L.n_chunks + 1;
-    const size_t slot_bytes = (L.W + OVER + 4096 + 4095) & ~(size_t)4095;
-    pthread_mutex_init(&L.mu, NULL);
-    pthread_cond_init(&L.cv, NULL);
-    if (posix_memalign((void **)&stage_base, 4096, slot_bytes * (size_t)L.n_st) != 0) { stage_base = NULL; goto done; }
     blocks = (pssbam_bgzf_block *)malloc(sizeof *blocks * BLOCKS_PER_SCAN);
     grp = (pssbam_bgzf_block *)malloc(sizeof *grp * BLOCKS_PER_SCAN);
     if (!blocks || !grp) goto done;
-    for (int i = 0; i < L.n_st; i++) {
-        L.st[i].buf = stage_base + (size_t)i * slot_bytes;
-        L.st[i].free_for = i;
-        L.st[i].loaded = -1;
-        L.st[i].pre = (pssbam_bgzf_block *)malloc(sizeof(pssbam_bgzf_block) * BLOCKS_PER_SCAN); /* NULL: no pre-scan, that is all */
-    }
-    if (!getenv("PSSBAM_NO_PIN")) registered = pssbam_host_register(stage_base, slot_bytes * (size_t)L.n_st) == 0;
-    {
-        long cpus = sysconf(_SC_NPROCESSORS_ONLN);
-        int want = (int)env_size("PSSBAM_LOADER_THREADS", n_gpus > 2 ? 4 * (size_t)n_gpus : 8);
-        if (want > 32) want = 32;
-        if (cpus > 0 && want > cpus) want = (int)cpus;
-        if ((long)want > L.n_chunks) want = (int)L.n_chunks;
-        for (int t = 0; t < want; t++)
-            if (pthread_create(&th[n_th], NULL, loader_main, &L) == 0) n_th++;
-        if (!n_th) goto done;
-    }
+    loader_pin(F);
 
     /* in-flight submits: (stage slot or -1, engine, ticket); a stage slot is handed back to the loaders
      * when the last submit that reads it has been copied */
@@ -344,19 +428,16 @@ int run_device_feed(pssbam_engine *const *eng, int n_gpus, const char *path, siz
                 n_prescanned, L.n_chunks, t_submit, t_wait_copy);
     rc = 0;
 done:
-    pthread_mutex_lock(&L.mu);
-    L.stop = 1;
-    pthread_cond_broadcast(&L.cv);
-    pthread_mutex_unlock(&L.mu);
-    for (int t = 0; t < n_th; t++) pthread_join(th[t], NULL);
-    if (rc) for (int g = 0; g < n_gpus; g++) (void)pssbam_engine_sync(eng[g]); /* nothing may still read the staging slots */
-    if (registered) pssbam_host_unregister(stage_base);
-    for (int i = 0; i < L.n_st; i++) free(L.st[i].pre);
-    free(stage_base);
+    if (rc) {   /* nothing may still read the staging slots */
+        pthread_mutex_lock(&L.mu);
+        L.stop = 1;
+        pthread_cond_broadcast(&L.cv);
+        pthread_mutex_unlock(&L.mu);
+        for (int g = 0; g < n_gpus; g++) (void)pssbam_engine_sync(eng[g]);
+    }
+#undef L
+    loader_close(F);
     free(blocks);
     free(grp);
-    if (L.fd >= 0) close(L.fd);
-    pthread_mutex_destroy(&L.mu);
-    pthread_cond_destroy(&L.cv);
     return rc;
 }

@@ -25,4 +25,12 @@ int device_feed_enabled(void);
  * record.  0 = done (see fs->fallback), -1 = failed after printing a diagnostic. */
 int run_device_feed(pssbam_engine *const *eng, int n_gpus, const char *path, size_t header_bytes, int run, int verbose,
                     device_feed_stats *fs);
+
+/* Start-up overlap for the front ends (one GPU): opens the file and starts the loader threads at once,
+ * so the first windows sit in the staging slots by the time the genome is on the device;
+ * run_device_feed() on the same path takes the loader over.  _pin page-locks the slots (needs the HIP
+ * runtime up), _cancel drops a loader nobody took. */
+void device_feed_prefetch(const char *path);
+void device_feed_prefetch_pin(void);
+void device_feed_prefetch_cancel(void);
 #endif

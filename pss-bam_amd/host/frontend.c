@@ -38,6 +38,7 @@ static void *warmup_main(void *arg)
     for (int g = 0; g < n; g++) (void)pssbam_warmup(g); /* failures surface in pssbam_engine_create */
     if (early_rd && early_light && !getenv("PSSBAM_OVERSUBSCRIBE"))
         for (int g = 0; g < n; g++) (void)pssbam_feed_reserve(g); /* the device feed's buffers, while the FASTA loads (best effort) */
+    if (early_rd && early_light) device_feed_prefetch_pin(); /* the loader's staging slots (already being filled) */
     if (early_rd && !early_light && !getenv("PSSBAM_NO_PIN")) {
         void *base;
         size_t bytes;
@@ -73,6 +74,7 @@ void frontend_warmup_start(const char *aln_path)
                                : bam_reader_open_slots(aln_path, 0, 0, feed_slots(env_gpu_count()), err, sizeof err);
         /* (a failure is reported by run_tally's own open) */
         if (early_rd) strcpy(early_path, aln_path);
+        if (early_rd && early_light) device_feed_prefetch(aln_path); /* its loader threads read the first windows meanwhile */
     }
     warmup_running = pthread_create(&warmup_thread, NULL, warmup_main, NULL) == 0;
 }
@@ -365,6 +367,7 @@ int run_tally(const pssbam_config *cfg, Genome *genome, const char *aln_path, in
     rc = 0;
 done:
     t_mark = now_s();
+    device_feed_prefetch_cancel(); /* (a loader opened ahead of time that no feed took over) */
     if (!(frontend_fast_exit && rc == 0)) {
         for (int g = 0; g < n_gpus; g++)
             if (eng[g]) pssbam_engine_destroy(eng[g]);

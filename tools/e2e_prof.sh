@@ -17,5 +17,5 @@ PY
 PSSBAM_CLEAN_EXIT=1 PSSBAM_STATS=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- pss-bam_amd/bin/pss-bam -F /tmp/e2e_in/ref.fa -B /tmp/e2e_in/reads.bam -o /tmp/e2e_in/out -r 25 > $OUT/run.log 2>&1
 grep -E "device feed|phases|gpus=" $OUT/run.log
 find $OUT/stats -name "*kernel_stats.csv" -exec cat {} \; | cut -c1-200
-cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
+cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv; cp $(find $OUT/stats -name "*kernel_trace.csv" | head -1) $OUT/kernel_trace.csv
 rm -rf /tmp/e2e_in
