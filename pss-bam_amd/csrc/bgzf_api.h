@@ -109,6 +109,7 @@ extern "C" int pssbam_bgzf_inflate_device(void *hip_stream, const void *d_comp, 
     return PSSBAM_OK;
 }
 
+
 // Convenience for tests and tools: host BGZF bytes in -> inflated bytes out (host), everything in
 // between on the device.  *kernel_ms = device time of the inflate (+ CRC) kernels alone.
 extern "C" int pssbam_bgzf_inflate_host(int device, const void *bgzf, uint64_t nbytes, void *out, uint64_t out_cap, uint64_t *out_len,

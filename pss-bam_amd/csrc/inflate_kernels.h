@@ -61,28 +61,16 @@ constexpr int L_SYM = 0, D_SYM = 288, INF_N8 = 320;
 constexpr int INF_N32 = 9;
 constexpr uint32_t INF_LDS_BYTES = (INF_N16 * 2 + INF_N8 + INF_N32 * 4) * INF_WAVE;
 constexpr int INF_WAVES_PER_CU = 5;
-// Measured variants (tools/variant_scan.sh, profiles/r02_inflate_variants.txt): none moves the kernel by
-// more than its run-to-run noise -- it is bound by round trips to a thrashing L2, not by request counts
-// (profiles/r02_inflate_pmc_mem.txt; the per-CU address path is 30 % busy) -- so the defaults are the
-// forms that cost nothing and ask the memory system for less.
-#ifndef INF_IN16
-#define INF_IN16 1        // stream read 16 bytes per request (0: a dword per request)             +1 %
-#endif
-#ifndef INF_TAIL2
-#define INF_TAIL2 1       // tails of a copy in at most two overlapping stores (0: 4 + 2 + 1 byte pieces)  0 %
-#endif
-#ifndef INF_LITMERGE
-#define INF_LITMERGE 0    // a literal run leaves as one store (0: a byte store per literal)          -1 %
-#endif
-#ifndef INF_SHORTMATCH
-#define INF_SHORTMATCH 0  // far matches of <= 16 bytes: one 16-byte load (0: always two)             -3 %
-#endif
-#ifndef INF_PAT16
-#define INF_PAT16 1       // period 1/2/4 runs stored 16 bytes per request (0: 8)                    +1 %
-#endif
-#ifndef INF_LIT_RUN
-#define INF_LIT_RUN 4u    // literals a lane may emit before the wave turns to the pending matches (2..12 measured: 291..275 GB/s)
-#endif
+// Literals a lane may emit before the wave turns to the pending matches (2..32 measured; 4 is best on every kind of
+// BAM tried, profiles/r02_inflate_variants.txt).
+constexpr uint32_t INF_LIT_RUN = 4u;
+// Tried and dropped (profiles/r02_inflate_variants.txt has the numbers): a "one wait per step" data loop -- the
+// loads of a step issued unconditionally at its top, the copy stored a step later, literals collected in a
+// register -- to get the memory round trip of a match off the critical path.  The compiled kernel waits with
+// vmcnt(0) wherever a loaded register is first touched, and the register allocator touches them early (copies
+// into other registers), so the overlap never materialised: 184 vs 262 GB/s on a constant-QUAL BAM, 71 vs 81
+// GB/s with 40-level quality strings.  What would: hand-scheduled waits (inline-asm loads + s_waitcnt with a
+// build-time ISA check), or two streams per lane.
 
 struct LaneLds {  // this lane's view of the three interleaved arrays
     // Interleaving is by DWORD: entry i of lane l sits in dword (i / per_dword) * 64 + l, so whatever
@@ -109,24 +97,24 @@ struct LaneLds {  // this lane's view of the three interleaved arrays
     }
 };
 
-#if INF_IN16
 struct BitReader {
-    const uint32_t *p;     // next aligned dword group to fetch
+    const uint32_t *p;     // next dword group to fetch
     const uint32_t *end;   // first dword that must not be read
     uint64_t buf;
     uint32_t cnt;          // valid bits in buf
     uint32_t rc;           // dwords left in the reservoir (r0 = the next two, r1 = the two behind them)
     uint64_t r0, r1;
-    uint4 ahead;           // the 16 bytes behind the reservoir, requested when the reservoir was filled
+    uint64_t n0, n1;       // the 16 bytes behind the reservoir, arrived (n_valid) ...
+    uint32_t n_valid;
+    uint4 ahead;           // ... and the 16 bytes behind those, in flight
     uint64_t consumed;     // bits handed out
     uint64_t limit;        // payload bits
 
     // The stream is read 16 bytes per request (a dword per request had every 128-byte line looked up --
-    // and, with 80 000 streams thrashing L2, often fetched -- four times as often), and the group that
-    // enters the reservoir was requested a whole reservoir EARLIER: its wait only covers memory operations
-    // older than that request (vmcnt retires in order), so a refill does not drain the stores the lane has
-    // issued since.
-    __device__ __forceinline__ void fetch() {
+    // and, with 80 000 streams thrashing L2, often fetched -- four times as often) through a queue of three
+    // groups: the reservoir being consumed, one group that has arrived (n), one requested (ahead = the 16
+    // bytes at p).  Beyond the end of the buffer the stream reads as zeros (overrun() tells).
+    __device__ __forceinline__ void request() {
         if (p + 4 <= end) __builtin_memcpy(&ahead, p, 16);
         else {
             ahead.x = p < end ? p[0] : 0u;
@@ -134,16 +122,27 @@ struct BitReader {
             ahead.z = p + 2 < end ? p[2] : 0u;
             ahead.w = p + 3 < end ? p[3] : 0u;
         }
-        p += 4;
     }
-    __device__ __forceinline__ void init() { buf = 0; cnt = 0; rc = 0; r0 = r1 = 0; consumed = 0; }
+    __device__ __forceinline__ void init() { buf = 0; cnt = 0; rc = 0; r0 = r1 = n0 = n1 = 0; n_valid = 0; consumed = 0; }
+    __device__ __forceinline__ void take_ahead() {   // (the first use of `ahead` since request(): a wait)
+        if (!n_valid) {
+            n0 = (uint64_t)ahead.x | ((uint64_t)ahead.y << 32);
+            n1 = (uint64_t)ahead.z | ((uint64_t)ahead.w << 32);
+            n_valid = 1u;
+            p += 4;
+        }
+    }
+    __device__ __forceinline__ void top_up() {
+        if (!n_valid) {
+            take_ahead();
+            request();
+        }
+    }
     __device__ __forceinline__ void refill() {
         if (cnt <= 32u) {
             if (rc == 0u) {
-                r0 = (uint64_t)ahead.x | ((uint64_t)ahead.y << 32);
-                r1 = (uint64_t)ahead.z | ((uint64_t)ahead.w << 32);
-                rc = 4u;
-                fetch();
+                top_up();
+                r0 = n0; r1 = n1; rc = 4u; n_valid = 0u;
             }
             buf |= (r0 & 0xFFFFFFFFull) << cnt;
             cnt += 32u;
@@ -161,41 +160,6 @@ struct BitReader {
     }
     __device__ __forceinline__ bool overrun() const { return consumed > limit; }
 };
-#else
-struct BitReader {
-    const uint32_t *p;     // next aligned dword to fetch
-    const uint32_t *end;   // first dword that must not be read
-    uint64_t buf;
-    uint32_t cnt;          // valid bits in buf
-    uint32_t ahead;        // the dword at p[-1], fetched one refill early
-    uint64_t consumed;     // bits handed out
-    uint64_t limit;        // payload bits
-
-    // The dword that enters the bit buffer was requested at the PREVIOUS refill: its wait only
-    // covers memory operations older than that request (vmcnt retires in order), so a refill no
-    // longer drains the stores the lane has issued since.
-    __device__ __forceinline__ void fetch() {
-        ahead = p < end ? *p : 0u;
-        p++;
-    }
-    __device__ __forceinline__ void init() { buf = 0; cnt = 0; consumed = 0; }
-    __device__ __forceinline__ void refill() {
-        if (cnt <= 32u) {
-            buf |= (uint64_t)ahead << cnt;
-            cnt += 32u;
-            fetch();
-        }
-    }
-    __device__ __forceinline__ uint32_t peek15() const { return __brev((uint32_t)buf) >> 17; }  // first-read bit = MSB
-    __device__ __forceinline__ void drop(uint32_t n) { buf >>= n; cnt -= n; consumed += n; }
-    __device__ __forceinline__ uint32_t take(uint32_t n) {  // n <= 16, caller has refilled
-        const uint32_t v = (uint32_t)buf & ((1u << n) - 1u);
-        drop(n);
-        return v;
-    }
-    __device__ __forceinline__ bool overrun() const { return consumed > limit; }
-};
-#endif
 
 // Canonical Huffman: builds upper[] (registers) and delta[] (LDS) from the per-length counts in
 // LDS at cnt_at (which it turns into the next-free-slot table offs[]).  false = over-subscribed.
@@ -252,13 +216,6 @@ __device__ __forceinline__ void store_u128(uint8_t *p, uint4 v) { __builtin_memc
 // The low n (<= 8) bytes of v in at most TWO store requests: a head piece and a tail piece of the same
 // power-of-two width that overlap in the middle (the memory system here is paid per request).
 __device__ __forceinline__ void store_tail(uint8_t *p, uint64_t v, uint32_t n) {
-#if !INF_TAIL2
-    if (n & 8u) { store_u64(p, v); return; }
-    if (n & 4u) { const uint32_t w = (uint32_t)v; __builtin_memcpy(p, &w, 4); p += 4; v >>= 32; }
-    if (n & 2u) { const uint16_t h = (uint16_t)v; __builtin_memcpy(p, &h, 2); p += 2; v >>= 16; }
-    if (n & 1u) *p = (uint8_t)v;
-    return;
-#endif
     if (n >= 8u) store_u64(p, v);
     else if (n >= 4u) {
         const uint32_t a = (uint32_t)v, b = (uint32_t)(v >> (8u * (n - 4u)));
@@ -274,15 +231,27 @@ __device__ __forceinline__ void store_tail(uint8_t *p, uint64_t v, uint32_t n) {
 __device__ __forceinline__ void store_tail16(uint8_t *p, uint64_t lo, uint64_t hi, uint32_t n) {
     if (n >= 16u) { uint4 q; q.x = (uint32_t)lo; q.y = (uint32_t)(lo >> 32); q.z = (uint32_t)hi; q.w = (uint32_t)(hi >> 32); store_u128(p, q); }
     else if (n > 8u) {
-#if !INF_TAIL2
-        store_u64(p, lo);
-        store_tail(p + 8, hi, n - 8u);
-        return;
-#endif
         const uint32_t sh = 8u * (n - 8u);            // 8..56
         store_u64(p, lo);
         store_u64(p + n - 8u, (lo >> sh) | (hi << (64u - sh)));
     } else store_tail(p, lo, n);
+}
+// len bytes of the periodic sequence whose first `dist` (< 8) bytes are the low bytes of pat
+__device__ __forceinline__ void store_run(uint8_t *dst, uint64_t pat, uint32_t dist, uint32_t len) {
+    pat &= (1ull << (8u * dist)) - 1ull;
+    for (uint32_t w = dist; w < 8u; w <<= 1) pat |= pat << (8u * w);
+    if ((8u % dist) == 0u) {
+        // period 1, 2 or 4 (the QUAL runs): the pattern repeats every 8 bytes, 16 per request
+        uint4 q;
+        q.x = q.z = (uint32_t)pat;
+        q.y = q.w = (uint32_t)(pat >> 32);
+        while (len >= 16u) { store_u128(dst, q); dst += 16; len -= 16u; }
+        store_tail16(dst, pat, pat, len);
+    } else {
+        const uint32_t step = (8u / dist) * dist;   // whole periods per 8-byte store
+        while (len >= 8u) { store_u64(dst, pat); dst += step; len -= step; }
+        store_tail(dst, pat, len);
+    }
 }
 
 // One BGZF block by one lane.  Returns INF_*.
@@ -296,7 +265,7 @@ __device__ uint32_t inflate_block(const uint8_t *comp, uint64_t comp_bytes, cons
         br.end = (const uint32_t *)(comp + ((comp_bytes + 3ull) & ~3ull));
         br.init();
         br.limit = (uint64_t)b.in_len * 8ull;
-        br.fetch();
+        br.request();
         br.refill();
         const uint32_t skip = 8u * (uint32_t)(a & 3ull);
         br.buf >>= skip;
@@ -453,27 +422,15 @@ __device__ uint32_t inflate_block(const uint8_t *comp, uint64_t comp_bytes, cons
                 // per (literal run + match), not per token.
                 int sym;
                 uint32_t run = 0;
-                uint64_t lits = 0;   // INF_LITMERGE: the run's bytes, stored in one go (at most two requests)
-                (void)lits;
                 for (;;) {
                     br.refill();
                     sym = huff_decode<15, true>(br, t, L_DELTA, L_SYM, 288, lu);
                     if (sym < 0 || sym >= 256) break;
-#if INF_LITMERGE
-                    lits |= (uint64_t)(uint32_t)sym << (8u * run);
-#else
                     if (pos + run >= isize) return INF_OVERRUN;
                     out[pos + run] = (uint8_t)sym;
-#endif
                     if (++run == INF_LIT_RUN) { sym = 512; break; }   // budget used up: give the matches their turn
                 }
-                if (run) {
-                    if (run > isize - pos) return INF_OVERRUN;
-#if INF_LITMERGE
-                    store_tail(out + pos, lits, run);
-#endif
-                    pos += run;
-                }
+                pos += run;
                 if (sym < 0) return INF_BAD_SYMBOL;
                 if (sym == 512) continue;
                 if (sym == 256) break;
@@ -510,11 +467,7 @@ __device__ uint32_t inflate_block(const uint8_t *comp, uint64_t comp_bytes, cons
                 if (dist >= 64u) {
                     // far matches (the usual case in a BAM: the previous record)
                     const uint8_t *src = dst - dist;
-                    if (INF_SHORTMATCH && len <= 16u) {
-                        // most matches are short: one request in, at most two out
-                        const uint4 a = load_u128(src);
-                        store_tail16(dst, (uint64_t)a.x | ((uint64_t)a.y << 32), (uint64_t)a.z | ((uint64_t)a.w << 32), len);
-                    } else {
+                    {
                         // 32 bytes per step, and the loads of step i+1 are issued BEFORE the stores of step i (they
                         // cannot overlap them: src + 64 <= dst) -- the wait for a load then does not include the
                         // younger stores
@@ -549,20 +502,7 @@ __device__ uint32_t inflate_block(const uint8_t *comp, uint64_t comp_bytes, cons
                         pat = 0;
                         for (uint32_t i = 0; i < dist; i++) pat |= (uint64_t)dst[(int)i - (int)dist] << (8u * i);
                     }
-                    pat &= dist >= 8u ? ~0ull : (1ull << (8u * dist)) - 1ull;
-                    for (uint32_t w = dist; w < 8u; w <<= 1) pat |= pat << (8u * w);
-                    if (INF_PAT16 && (8u % dist) == 0u) {
-                        // period 1, 2 or 4 (the QUAL runs): the pattern repeats every 8 bytes, 16 per request
-                        uint4 q;
-                        q.x = q.z = (uint32_t)pat;
-                        q.y = q.w = (uint32_t)(pat >> 32);
-                        while (len >= 16u) { store_u128(dst, q); dst += 16; len -= 16u; }
-                        store_tail16(dst, pat, pat, len);
-                    } else {
-                        const uint32_t step = (8u / dist) * dist;   // whole periods per 8-byte store
-                        while (len >= 8u) { store_u64(dst, pat); dst += step; len -= step; }
-                        store_tail(dst, pat, len);
-                    }
+                    store_run(dst, pat, dist, len);
                 }
             }
             if (br.overrun()) return INF_TRUNCATED;

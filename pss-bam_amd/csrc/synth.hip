@@ -221,7 +221,7 @@ int synth_fasta_host(const synth_cfg *c, const char *path, uint32_t first, uint3
 // on-disk form the front ends consume; used by the end-to-end measurements and CLI tests.
 // layout 0: BGZF blocks the way htslib writes them -- the header in its own block(s), then whole
 // records per block (a block is closed when the next record would not fit 0xff00 bytes; bam_write1
-// calls bgzf_flush_try), so every block starts on a record boundary.  layout 1: the stream cut
+// calls bgzf_flush_try), so every block starts on a record boundary.  layout bit 0: the stream cut
 // every 0xff00 bytes regardless of records (what htsjdk-style writers produce).
 int synth_bam_file_host(const synth_cfg *c, uint64_t slot0, uint64_t n, const char *path, int level, int threads,
                         int layout) {
@@ -265,10 +265,39 @@ int synth_bam_file_host(const synth_cfg *c, uint64_t slot0, uint64_t n, const ch
         raw.resize(carry.size() + tot);
         std::copy(carry.begin(), carry.end(), raw.begin());
         if (m) synth_records_host(c, slot0 + a, m, offs.data(), raw.data() + carry.size(), threads);
+        if (m && (layout & 6)) {
+            // QUAL of the named configurations is constant ("QUAL all I"), which DEFLATE turns into
+            // one long match per read; these two modes give the inflate something closer to a sequencer's
+            // output to chew on (the tally never looks past QUAL[0]): 2 = four quality bins (NovaSeq-style:
+            // 37 / 25 / 11 / 2 with probability .80 / .12 / .06 / .02), 4 = 40 levels, skewed to the top
+            uint8_t *base = raw.data() + carry.size();
+            const uint32_t *of = offs.data();
+            const bool bins = (layout & 2) != 0;
+            const uint64_t seed = c->seed * 0x9E3779B97F4A7C15ull + (slot0 + a);
+            parallel_for(m, threads, [=](uint64_t r0, uint64_t r1) {
+                for (uint64_t i = r0; i < r1; i++) {
+                    uint8_t *rec = base + of[i];
+                    uint32_t l_seq, w3, w4;
+                    memcpy(&w3, rec + 12, 4); memcpy(&w4, rec + 16, 4); memcpy(&l_seq, rec + 20, 4);
+                    uint8_t *q = rec + 36 + (w3 & 0xFFu) + 4u * (w4 & 0xFFFFu) + (l_seq + 1u) / 2u;
+                    uint64_t x = seed + i * 0xD1342543DE82EF95ull;
+                    for (uint32_t k = 0; k < l_seq; k++) {
+                        x ^= x >> 33; x *= 0xFF51AFD7ED558CCDull; x ^= x >> 29; x += 0x9E3779B97F4A7C15ull;   // a new word per base
+                        const uint32_t u = (uint32_t)(x >> 40) & 0xFFFFu;
+                        if (bins) q[k] = u < 52429u ? 37 : u < 60293u ? 25 : u < 64225u ? 11 : 2;
+                        else {
+                            const uint32_t v = (uint32_t)(x >> 20) & 0xFFFFu;
+                            const uint32_t lo = u < v ? u : v;          // min of two uniforms: density falls linearly
+                            q[k] = (uint8_t)(40u - lo * 39u / 65536u);  // 40 most likely ... 2 least
+                        }
+                    }
+                }
+            });
+        }
         const bool last = a + m >= n;
         cut.clear();
         cut.push_back(0);
-        if (layout == 0) {
+        if ((layout & 1) == 0) {
             // carry = the BAM header (first round only; flushed as its own blocks), never records:
             // in this layout every round ends on a record boundary
             const size_t lead = carry.size();

@@ -135,8 +135,12 @@ def fasta_host(cfg: SynthCfg, path, first: int = 0, count: int | None = None, wi
         raise OSError(f"cannot write {path}")
 
 
-def bam_file_host(cfg: SynthCfg, slot0: int, n: int, path, level: int = 1, threads: int = 8, ragged: bool = False) -> None:
+def bam_file_host(cfg: SynthCfg, slot0: int, n: int, path, level: int = 1, threads: int = 8, ragged: bool = False,
+                  quals: str = "const") -> None:
     """BGZF-compressed BAM file (header + records of slots [slot0, slot0+n)).  Default block layout is
-    htslib's (whole records per block); ragged=True cuts the stream every 0xff00 bytes instead."""
-    if lib().synth_bam_file_host(C.byref(cfg), slot0, n, str(path).encode(), level, threads, int(ragged)) != 0:
+    htslib's (whole records per block); ragged=True cuts the stream every 0xff00 bytes instead.
+    quals: "const" (the named configurations: QUAL all 'I'), "binned" (four quality bins, i.i.d. per base)
+    or "full" (40 levels) -- only the compressed size and the inflate's work change, never the tables."""
+    layout = int(ragged) | {"const": 0, "binned": 2, "full": 4}[quals]
+    if lib().synth_bam_file_host(C.byref(cfg), slot0, n, str(path).encode(), level, threads, layout) != 0:
         raise OSError(f"cannot write {path}")

@@ -30,6 +30,7 @@ ap.add_argument("--scale-genome", type=float, default=1.0)
 ap.add_argument("--config", default="C3")
 ap.add_argument("--level", type=int, default=1)
 ap.add_argument("--ragged", action="store_true", help="BGZF blocks cut every 0xff00 bytes regardless of records (htsjdk-style)")
+ap.add_argument("--quals", default="const", choices=["const", "binned", "full"], help="QUAL model of the generated BAM (synth.bam_file_host)")
 args = ap.parse_args(argv)
 pkg = ge.load_pkg()
 from pss_bam_amd import synth  # noqa: E402
@@ -42,7 +43,7 @@ cfg = synth.make_cfg(**d)
 tmp = Path(tempfile.mkdtemp(prefix="pssbam_scan_", dir=os.environ.get("TMPDIR", "/tmp")))
 fa, bam = tmp / "ref.fa", tmp / "reads.bam"
 synth.fasta_host(cfg, fa, threads=threads)
-synth.bam_file_host(cfg, 0, args.reads, bam, level=args.level, threads=threads, ragged=args.ragged)
+synth.bam_file_host(cfg, 0, args.reads, bam, level=args.level, threads=threads, ragged=args.ragged, quals=args.quals)
 print(f"[feed_scan] {args.reads} reads, BAM {bam.stat().st_size / 1e9:.2f} GB, FASTA {fa.stat().st_size / 1e9:.2f} GB", flush=True)
 ref_counts = None
 for st in settings:

@@ -27,6 +27,7 @@ ap.add_argument("--reads", type=int, default=20_000_000)
 ap.add_argument("--level", type=int, default=1)
 ap.add_argument("--config", default="C3")
 ap.add_argument("--ragged", action="store_true")
+ap.add_argument("--quals", default="const", choices=["const", "binned", "full"], help="QUAL model of the generated BAM (synth.bam_file_host)")
 ap.add_argument("--no-crc", action="store_true")
 ap.add_argument("--repeats", type=int, default=3, help="kernel runs; the best is reported (1 = a cold first run, what a short-lived command sees)")
 ap.add_argument("--no-output", action="store_true", help="skip the D2H copy and the zlib comparison (large files)")
@@ -45,7 +46,7 @@ cfg = synth.make_cfg(**d)
 tmp = Path(tempfile.mkdtemp(prefix="pssbam_inf_", dir=os.environ.get("TMPDIR", "/tmp")))
 bam = tmp / "reads.bam"
 t = time.time()
-synth.bam_file_host(cfg, 0, args.reads, bam, level=args.level, threads=threads, ragged=args.ragged)
+synth.bam_file_host(cfg, 0, args.reads, bam, level=args.level, threads=threads, ragged=args.ragged, quals=args.quals)
 t_gen = time.time() - t
 raw = np.fromfile(bam, dtype=np.uint8)
 res = pkg.bgzf_inflate(raw, check_crc=not args.no_crc, repeats=args.repeats, want_output=not args.no_output)
