@@ -72,26 +72,38 @@ int ensure_xpow(int dev, uint32_t **out) {
 
 static_assert(sizeof(pssbam_bgzf_block) == sizeof(pssbam::BgzfBlock), "public and device block descriptors must match");
 
-extern "C" int pssbam_bgzf_inflate_device(void *hip_stream, const void *d_comp, uint64_t comp_bytes, pssbam_bgzf_block *d_blocks,
-                                          uint32_t n_blocks, void *d_out, int check_crc) {
+constexpr int INFLATE_LOOP_DEFAULT = 1;   // what the feed and the host convenience call use (their buffers have the slack)
+
+// loop: 0 = the in-place data loop, 1 = one wait per step (csrc/inflate_kernels.h); $PSSBAM_INFLATE_LOOP overrides
+// (except for -2 = the public entry point, which is always 0).  The second loop requests up to 24 bytes past a block's end in d_out and re-reads the
+// last 16 bytes of d_comp: callers that ask for it own buffers with that slack.
+static int launch_inflate(hipStream_t st, const void *d_comp, uint64_t comp_bytes, pssbam_bgzf_block *d_blocks, uint32_t n_blocks,
+                          void *d_out, int check_crc, int loop) {
     if (!n_blocks) return PSSBAM_OK;
     if (!d_comp || !d_blocks || !d_out) return fail(PSSBAM_EINVAL, "null buffer");
     if ((uintptr_t)d_comp & 3u) return fail(PSSBAM_EINVAL, "d_comp must be 4-byte aligned");
     int dev = 0, n_cu = 0;
     HIP_TRY(hipGetDevice(&dev));
     HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-    hipStream_t st = (hipStream_t)hip_stream;
     static bool attr_set[64] = {false};
     if (!attr_set[dev & 63]) {
-        HIP_TRY(hipFuncSetAttribute((const void *)pssbam::bgzf_inflate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pssbam::INF_LDS_BYTES));
+        HIP_TRY(hipFuncSetAttribute((const void *)pssbam::bgzf_inflate_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pssbam::INF_LDS_BYTES));
+        HIP_TRY(hipFuncSetAttribute((const void *)pssbam::bgzf_inflate_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pssbam::INF_LDS_BYTES_DEFER));
         attr_set[dev & 63] = true;
     }
+    if (loop == -2) loop = 0;   // (not negotiable)
+    else if (const char *lm = getenv("PSSBAM_INFLATE_LOOP")) loop = atoi(lm) != 0;
+    if (comp_bytes < 64u) loop = 0;
     const uint32_t groups = (n_blocks + pssbam::INF_WAVE - 1) / pssbam::INF_WAVE;
     const char *gm = getenv("PSSBAM_INFLATE_WAVES_PER_CU");
     const uint32_t per_cu = gm && atoi(gm) > 0 ? (uint32_t)atoi(gm) : (uint32_t)pssbam::INF_WAVES_PER_CU;
     const uint32_t grid = std::min<uint32_t>(groups, (uint32_t)n_cu * per_cu);
-    hipLaunchKernelGGL(pssbam::bgzf_inflate_kernel, dim3(grid), dim3(pssbam::INF_WAVE), pssbam::INF_LDS_BYTES, st, (const uint8_t *)d_comp, comp_bytes,
-                       (pssbam::BgzfBlock *)d_blocks, n_blocks, (uint8_t *)d_out);
+    if (loop > 0)
+        hipLaunchKernelGGL(pssbam::bgzf_inflate_kernel<true>, dim3(grid), dim3(pssbam::INF_WAVE), pssbam::INF_LDS_BYTES_DEFER, st, (const uint8_t *)d_comp,
+                           comp_bytes, (pssbam::BgzfBlock *)d_blocks, n_blocks, (uint8_t *)d_out);
+    else
+        hipLaunchKernelGGL(pssbam::bgzf_inflate_kernel<false>, dim3(grid), dim3(pssbam::INF_WAVE), pssbam::INF_LDS_BYTES, st, (const uint8_t *)d_comp,
+                           comp_bytes, (pssbam::BgzfBlock *)d_blocks, n_blocks, (uint8_t *)d_out);
     HIP_TRY(hipGetLastError());
     if (check_crc) {
         uint32_t *xpow = nullptr;
@@ -107,6 +119,11 @@ extern "C" int pssbam_bgzf_inflate_device(void *hip_stream, const void *d_comp, 
         HIP_TRY(hipGetLastError());
     }
     return PSSBAM_OK;
+}
+
+extern "C" int pssbam_bgzf_inflate_device(void *hip_stream, const void *d_comp, uint64_t comp_bytes, pssbam_bgzf_block *d_blocks,
+                                          uint32_t n_blocks, void *d_out, int check_crc) {
+    return launch_inflate((hipStream_t)hip_stream, d_comp, comp_bytes, d_blocks, n_blocks, d_out, check_crc, -2);   // a caller's buffers: no over-reads
 }
 
 
@@ -142,7 +159,7 @@ extern "C" int pssbam_bgzf_inflate_host(int device, const void *bgzf, uint64_t n
     };
 #define TRY_C(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { cleanup(); return fail(PSSBAM_EHIP, "%s failed: %s", #expr, hipGetErrorString(_e)); } } while (0)
     TRY_C(hipMalloc(&d_comp, nbytes + 16));
-    TRY_C(hipMalloc(&d_out, total + 16));
+    TRY_C(hipMalloc(&d_out, total + 64));   // (slack for the one-wait-per-step loop's requests)
     TRY_C(hipMalloc(&d_blocks, (size_t)n * sizeof(pssbam_bgzf_block)));
     TRY_C(hipMemset(d_comp + nbytes, 0, 16));
     TRY_C(hipMemcpy(d_comp, bgzf, nbytes, hipMemcpyHostToDevice));
@@ -153,7 +170,7 @@ extern "C" int pssbam_bgzf_inflate_host(int device, const void *bgzf, uint64_t n
     float best = 1e30f;
     for (int r = 0; r < repeats && rc == PSSBAM_OK; r++) {
         TRY_C(hipEventRecord(e0, nullptr));
-        rc = pssbam_bgzf_inflate_device(nullptr, d_comp, nbytes, d_blocks, (uint32_t)n, d_out, check_crc);
+        rc = launch_inflate(nullptr, d_comp, nbytes, d_blocks, (uint32_t)n, d_out, check_crc, INFLATE_LOOP_DEFAULT);
         if (rc) break;
         TRY_C(hipEventRecord(e1, nullptr));
         TRY_C(hipEventSynchronize(e1));
@@ -309,8 +326,8 @@ static int feed_flush(pssbam_engine *e) {
     hipEvent_t ev0 = take_event(e), ev1 = take_event(e);
     if (!ev0 || !ev1) return fail(PSSBAM_EHIP, "hipEventCreate failed");
     HIP_TRY(hipEventRecord(ev0, e->stream));
-    rc = pssbam_bgzf_inflate_device(e->stream, s.d_comp, s.comp_used, (pssbam_bgzf_block *)s.d_blocks, (uint32_t)nb, s.d_out,
-                                    getenv("PSSBAM_NO_CRC") ? 0 : 1);
+    rc = launch_inflate(e->stream, s.d_comp, s.comp_used, (pssbam_bgzf_block *)s.d_blocks, (uint32_t)nb, s.d_out, getenv("PSSBAM_NO_CRC") ? 0 : 1,
+                        INFLATE_LOOP_DEFAULT);
     if (rc) return rc;
     // the record chain of the whole super-batch: per-block pieces, linked and checked
     {

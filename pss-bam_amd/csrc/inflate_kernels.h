@@ -61,16 +61,24 @@ constexpr int L_SYM = 0, D_SYM = 288, INF_N8 = 320;
 constexpr int INF_N32 = 9;
 constexpr uint32_t INF_LDS_BYTES = (INF_N16 * 2 + INF_N8 + INF_N32 * 4) * INF_WAVE;
 constexpr int INF_WAVES_PER_CU = 5;
-// Literals a lane may emit before the wave turns to the pending matches (2..32 measured; 4 is best on every kind of
-// BAM tried, profiles/r02_inflate_variants.txt).
-constexpr uint32_t INF_LIT_RUN = 4u;
-// Tried and dropped (profiles/r02_inflate_variants.txt has the numbers): a "one wait per step" data loop -- the
-// loads of a step issued unconditionally at its top, the copy stored a step later, literals collected in a
-// register -- to get the memory round trip of a match off the critical path.  The compiled kernel waits with
-// vmcnt(0) wherever a loaded register is first touched, and the register allocator touches them early (copies
-// into other registers), so the overlap never materialised: 184 vs 262 GB/s on a constant-QUAL BAM, 71 vs 81
-// GB/s with 40-level quality strings.  What would: hand-scheduled waits (inline-asm loads + s_waitcnt with a
-// build-time ISA check), or two streams per lane.
+// Two data loops (inflate_block<DEFER>):
+//   DEFER = false  "in place": a copy is loaded, waited for and stored where it is decoded; literals leave as byte
+//                  stores, at most INF_RUN_INPLACE per step.
+//   DEFER = true   "one wait per step": every step starts by REQUESTING what the next memory phase needs -- the source
+//                  of the copy decoded in the previous step and the next 16 stream bytes -- then decodes (no memory
+//                  operations), then waits ONCE, stores the copy and its own literals.
+// Why the second one, and why its requests are LDS-DMA: in the compiled in-place loop every global_load is followed
+// by s_waitcnt vmcnt(0) within a few instructions (the loaded registers are copied into loop-carried ones at once),
+// so each load costs a full round trip AND drains the stores in front of it -- "prefetched" stream reads included
+// (SQ_WAIT_ANY 68 % of the wave cycles, profiles/r02_inflate_variants.txt).  Writing the same schedule with ordinary
+// loads does not help: the register allocator touches the loaded registers early and the wait moves there (measured:
+// slower than in place).  global_load_lds_dwordx4 from inline asm lands the data in LDS without the compiler knowing
+// a load is in flight; the one s_waitcnt vmcnt(0) of a step is written by hand, behind the decode phase.
+constexpr uint32_t INF_RUN_INPLACE = 4u, INF_RUN_DEFER = 8u;   // literals a lane may take per step (DEFER: they travel in one register)
+// landing planes of the DEFER loop: three times 16 bytes per lane behind the decode tables (still five waves per CU)
+constexpr uint32_t INF_LAND_BYTES = 3u * 16u * INF_WAVE;
+constexpr uint32_t INF_LDS_BYTES_DEFER = INF_LDS_BYTES + INF_LAND_BYTES;
+static_assert(INF_LDS_BYTES_DEFER * INF_WAVES_PER_CU <= 160u * 1024u, "five waves of the DEFER loop must fit the CU's LDS");
 
 struct LaneLds {  // this lane's view of the three interleaved arrays
     // Interleaving is by DWORD: entry i of lane l sits in dword (i / per_dword) * 64 + l, so whatever
@@ -138,17 +146,42 @@ struct BitReader {
             request();
         }
     }
-    __device__ __forceinline__ void refill() {
+    // bits that can be handed out without touching memory
+    __device__ __forceinline__ uint32_t avail() const { return cnt + 32u * rc + (n_valid ? 128u : 0u); }
+    __device__ __forceinline__ void refill_nomem() {   // caller: avail() covers what it is about to take
         if (cnt <= 32u) {
-            if (rc == 0u) {
-                top_up();
-                r0 = n0; r1 = n1; rc = 4u; n_valid = 0u;
-            }
+            if (rc == 0u) { r0 = n0; r1 = n1; rc = 4u; n_valid = 0u; }
             buf |= (r0 & 0xFFFFFFFFull) << cnt;
             cnt += 32u;
             r0 = (r0 >> 32) | (r1 << 32);
             r1 >>= 32;
             rc--;
+        }
+    }
+    __device__ __forceinline__ void refill() {
+        if (cnt <= 32u) {
+            if (rc == 0u) top_up();
+            refill_nomem();
+        }
+    }
+    // DEFER loop: the address its stream request reads (never across the end of the buffer: the buffer's last 16
+    // bytes instead) and the hand-over of what arrived
+    __device__ __forceinline__ const uint32_t *request_addr() const { return p + 4 <= end ? p : end - 4; }
+    __device__ __forceinline__ void take_group(uint4 g) {
+        if (!n_valid) {
+            n0 = (uint64_t)g.x | ((uint64_t)g.y << 32);
+            n1 = (uint64_t)g.z | ((uint64_t)g.w << 32);
+            if (p + 4 > end) {
+                // the group straddles the end: g = [end - 4, end), whose LAST dwords are this group's first ones;
+                // what lies beyond the buffer reads as zero
+                const uint64_t k = (uint64_t)((p + 4) - end);   // dwords of the group that do not exist
+                if (k >= 4u) n0 = n1 = 0;
+                else if (k == 3u) { n0 = n1 >> 32; n1 = 0; }
+                else if (k == 2u) { n0 = n1; n1 = 0; }
+                else { n0 = (n0 >> 32) | (n1 << 32); n1 >>= 32; }
+            }
+            n_valid = 1u;
+            p += 4;
         }
     }
     __device__ __forceinline__ uint32_t peek15() const { return __brev((uint32_t)buf) >> 17; }  // first-read bit = MSB
@@ -254,8 +287,19 @@ __device__ __forceinline__ void store_run(uint8_t *dst, uint64_t pat, uint32_t d
     }
 }
 
-// One BGZF block by one lane.  Returns INF_*.
-__device__ uint32_t inflate_block(const uint8_t *comp, uint64_t comp_bytes, const BgzfBlock &b, uint8_t *outbuf, const LaneLds &t) {
+// 16 bytes per lane, global -> LDS at lds_base + 16 * lane, without a register in between and without the compiler
+// knowing (m0 is compiler-reserved and cannot be named as a clobber: saved and restored)
+__device__ __forceinline__ void dma16_to_lds(uint32_t lds_base, const void *src) {
+    const uint32_t m0v = __builtin_amdgcn_readfirstlane(lds_base);
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(m0v) : "memory");
+}
+
+// One BGZF block by one lane.  Returns INF_*.  land: this wave's landing planes (DEFER only).
+template <bool DEFER>
+__device__ uint32_t inflate_block(const uint8_t *comp, uint64_t comp_bytes, const BgzfBlock &b, uint8_t *outbuf, const LaneLds &t,
+                                  uint8_t *land, uint32_t lane) {
     uint8_t *out = outbuf + b.out_off;
     const uint32_t isize = b.isize;
     BitReader br;
@@ -414,11 +458,116 @@ __device__ uint32_t inflate_block(const uint8_t *comp, uint64_t comp_bytes, cons
                 }
             }
             // ---- the compressed data of this deflate block ------------------------------------
+            if constexpr (DEFER) {
+            // (0) requests, (1) decode, (2) wait + stores; see the head of the file.  This step's copy is only
+            // classified in (2): short and not feeding on itself -> its source is what the next step requests,
+            // anything else is copied in place.  Program order keeps the bytes right: everything in front of a
+            // copy's source has been stored (issued) before the request is; at the end of a deflate block
+            // nothing is pending (its last step has no copy).
+            const uint32_t land0 = (uint32_t)(uintptr_t)land;   // LDS byte address of the planes
+            const uint8_t *lsrc = comp;     // what (0) reads: the pending copy's source, else the head of the buffer
+            uint8_t *pdst = out;
+            uint32_t plen = 0, pdist = 0;   // pending copy; pdist != 0: a run of period pdist (< 8) seeded by the 8 bytes in front of pdst
+            for (;;) {
+                dma16_to_lds(land0, lsrc);
+                dma16_to_lds(land0 + 16u * INF_WAVE, lsrc + 16);
+                dma16_to_lds(land0 + 32u * INF_WAVE, br.request_addr());
+                int sym = 512;   // 512: no token this step
+                uint32_t run = 0;
+                uint64_t lits = 0;
+                while (run < INF_RUN_DEFER && br.avail() >= 64u) {   // (a token takes at most 48 bits)
+                    br.refill_nomem();
+                    sym = huff_decode<15, true>(br, t, L_DELTA, L_SYM, 288, lu);
+                    if (sym < 0 || sym >= 256) break;
+                    lits |= (uint64_t)(uint32_t)sym << (8u * run);
+                    run++;
+                    sym = 512;
+                }
+                if (sym < 0) return INF_BAD_SYMBOL;
+                uint32_t len = 0, dist = 0;
+                if (sym > 256 && sym != 512) {
+                    if (sym > 285) return INF_BAD_SYMBOL;
+                    // length: 257..264 -> 3..10; 265..284 -> ((4 + (s-265)%4) << e) + 3 with e = (s-261)/4 extra bits; 285 -> 258
+                    const uint32_t s = (uint32_t)sym;
+                    if (s < 265u) len = s - 254u;
+                    else if (s == 285u) len = 258u;
+                    else {
+                        const uint32_t e = (s - 261u) >> 2;
+                        len = ((4u + ((s - 265u) & 3u)) << e) + 3u + br.take(e);
+                    }
+                    br.refill_nomem();
+                    const int ds = huff_decode<15, false>(br, t, D_DELTA, D_SYM, 30, du);
+                    if (ds < 0 || ds >= 30) return INF_BAD_DISTANCE;   // (>= 30: an unplaced slot of an incomplete code)
+                    const uint32_t d = (uint32_t)ds;
+                    if (d < 4u) dist = d + 1u;
+                    else {
+                        const uint32_t e = (d >> 1) - 1u;
+                        dist = ((2u + (d & 1u)) << e) + 1u + br.take(e);
+                    }
+                }
+                // ---- (2): what (0) requested has had the decode phase to arrive
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (plen) {
+                    const uint4 pa = *(const uint4 *)(land + 16u * lane);
+                    if (pdist) store_run(pdst, ((uint64_t)pa.z | ((uint64_t)pa.w << 32)) >> (8u * (8u - pdist)), pdist, plen);
+                    else if (plen > 16u) {
+                        const uint4 pb = *(const uint4 *)(land + 16u * INF_WAVE + 16u * lane);
+                        store_u128(pdst, pa);
+                        store_tail16(pdst + 16, (uint64_t)pb.x | ((uint64_t)pb.y << 32), (uint64_t)pb.z | ((uint64_t)pb.w << 32), plen - 16u);
+                    } else store_tail16(pdst, (uint64_t)pa.x | ((uint64_t)pa.y << 32), (uint64_t)pa.z | ((uint64_t)pa.w << 32), plen);
+                    plen = 0;
+                }
+                br.take_group(*(const uint4 *)(land + 32u * INF_WAVE + 16u * lane));
+                if (run) {
+                    if (run > isize - pos) return INF_OVERRUN;
+                    store_tail(out + pos, lits, run);
+                    pos += run;
+                }
+                if (sym == 256) { br.request(); break; }   // (the headers read the stream with ordinary loads again)
+                lsrc = comp;
+                if (len) {
+                    if (dist > pos) return INF_BAD_DISTANCE;
+                    if (len > isize - pos) return INF_OVERRUN;
+                    uint8_t *dst = out + pos;
+                    const uint8_t *src = dst - dist;
+                    if (dist < 8u && pos >= 16u) {
+                        lsrc = dst - 16;   // (the seed is the upper half of the first plane)
+                        pdst = dst; plen = len; pdist = dist;
+                    } else if (dist >= 8u && len <= 32u && dist >= len) {
+                        // (the 32 bytes requested may run past dst by up to 24: not-yet-written bytes of this block, of
+                        //  the next one or of the buffer's slack, none of which is stored)
+                        lsrc = src;
+                        pdst = dst; plen = len; pdist = 0u;
+                    } else if (dist >= 64u) {
+                        // long far matches, in place: 32 bytes per step, the loads of step i+1 issued before the stores of step i
+                        uint32_t n = len;
+                        uint4 a = load_u128(src), b = load_u128(src + 16);
+                        while (n > 32u) {
+                            const uint4 na = load_u128(src + 32), nb = load_u128(src + 48);   // (src + 64 <= dst)
+                            store_u128(dst, a);
+                            store_u128(dst + 16, b);
+                            a = na; b = nb;
+                            dst += 32; src += 32; n -= 32u;
+                        }
+                        if (n >= 16u) { store_u128(dst, a); dst += 16; n -= 16u; a = b; }
+                        store_tail16(dst, (uint64_t)a.x | ((uint64_t)a.y << 32), (uint64_t)a.z | ((uint64_t)a.w << 32), n);
+                    } else if (dist >= 8u) {
+                        // 8 <= dist < 64 and the copy feeds on itself or is long: 8 bytes at a time, in place
+                        uint32_t n = len;
+                        while (n >= 8u) { store_u64(dst, load_u64(src)); dst += 8; src += 8; n -= 8u; }
+                        if (n) store_tail(dst, load_u64(src), n);   // (src + n <= dst: the bytes used are old ones)
+                    } else {
+                        for (uint32_t i = 0; i < len; i++) dst[i] = dst[(int)i - (int)dist];   // a short period in the first bytes of a block
+                    }
+                    pos += len;
+                }
+            }
+            } else {
             for (;;) {
                 // Literal run first, in its own inner loop: a literal costs a decode and a fire-and-forget
                 // byte store, a match costs a load round trip -- and on a lock-stepped wave of 64 streams
                 // SOME lane has a match at nearly every step.  Letting every lane run through up to
-                // INF_LIT_RUN literals before the wave turns to the matches makes the round trip a cost
+                // INF_RUN_INPLACE literals before the wave turns to the matches makes the round trip a cost
                 // per (literal run + match), not per token.
                 int sym;
                 uint32_t run = 0;
@@ -428,7 +577,7 @@ __device__ uint32_t inflate_block(const uint8_t *comp, uint64_t comp_bytes, cons
                     if (sym < 0 || sym >= 256) break;
                     if (pos + run >= isize) return INF_OVERRUN;
                     out[pos + run] = (uint8_t)sym;
-                    if (++run == INF_LIT_RUN) { sym = 512; break; }   // budget used up: give the matches their turn
+                    if (++run == INF_RUN_INPLACE) { sym = 512; break; }   // budget used up: give the matches their turn
                 }
                 pos += run;
                 if (sym < 0) return INF_BAD_SYMBOL;
@@ -505,6 +654,7 @@ __device__ uint32_t inflate_block(const uint8_t *comp, uint64_t comp_bytes, cons
                     store_run(dst, pat, dist, len);
                 }
             }
+            }
             if (br.overrun()) return INF_TRUNCATED;
         } else {
             return INF_BAD_BLOCK;
@@ -516,6 +666,7 @@ __device__ uint32_t inflate_block(const uint8_t *comp, uint64_t comp_bytes, cons
 }
 
 // grid of single-wave workgroups, each wave takes 64 consecutive blocks at a time
+template <bool DEFER>
 __global__ void __launch_bounds__(INF_WAVE) bgzf_inflate_kernel(const uint8_t *comp, uint64_t comp_bytes, BgzfBlock *blocks,
                                                                 uint32_t n_blocks, uint8_t *out) {
     extern __shared__ __attribute__((aligned(16))) uint8_t inf_lds[];
@@ -529,7 +680,7 @@ __global__ void __launch_bounds__(INF_WAVE) bgzf_inflate_kernel(const uint8_t *c
             uint32_t st = INF_OK;
             // (a descriptor the caller got wrong must not become a wild address)
             if (b.isize > 65536u || b.in_off > comp_bytes || b.in_len > comp_bytes - b.in_off) st = INF_BAD_BLOCK;
-            else if (b.isize) st = inflate_block(comp, comp_bytes, b, out, t);
+            else if (b.isize) st = inflate_block<DEFER>(comp, comp_bytes, b, out, t, inf_lds + INF_LDS_BYTES, lane);
             blocks[i].status = st;
         }
     }

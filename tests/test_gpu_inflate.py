@@ -16,6 +16,12 @@ pytestmark = pytest.mark.gpu
 GOLD = Path(__file__).resolve().parent / "golden"
 
 
+@pytest.fixture(params=["in-place", "one-wait-per-step"], autouse=True)
+def inflate_loop(request, monkeypatch):
+    """every test of this module runs under both data loops of the inflate kernel (csrc/inflate_kernels.h)"""
+    monkeypatch.setenv("PSSBAM_INFLATE_LOOP", "0" if request.param == "in-place" else "1")
+
+
 @pytest.fixture(scope="module")
 def pkg():
     p = ge.load_pkg()
