@@ -77,8 +77,9 @@ constexpr int INFLATE_LOOP_DEFAULT = 1;   // what the feed and the host convenie
 // loop: 0 = the in-place data loop, 1 = one wait per step (csrc/inflate_kernels.h); $PSSBAM_INFLATE_LOOP overrides
 // (except for -2 = the public entry point, which is always 0).  The second loop requests up to 24 bytes past a block's end in d_out and re-reads the
 // last 16 bytes of d_comp: callers that ask for it own buffers with that slack.
+// out_bytes: what the batch inflates to (0 = unknown) -- picks the literal budget of the second loop.
 static int launch_inflate(hipStream_t st, const void *d_comp, uint64_t comp_bytes, pssbam_bgzf_block *d_blocks, uint32_t n_blocks,
-                          void *d_out, int check_crc, int loop) {
+                          void *d_out, int check_crc, int loop, uint64_t out_bytes) {
     if (!n_blocks) return PSSBAM_OK;
     if (!d_comp || !d_blocks || !d_out) return fail(PSSBAM_EINVAL, "null buffer");
     if ((uintptr_t)d_comp & 3u) return fail(PSSBAM_EINVAL, "d_comp must be 4-byte aligned");
@@ -98,12 +99,16 @@ static int launch_inflate(hipStream_t st, const void *d_comp, uint64_t comp_byte
     const char *gm = getenv("PSSBAM_INFLATE_WAVES_PER_CU");
     const uint32_t per_cu = gm && atoi(gm) > 0 ? (uint32_t)atoi(gm) : (uint32_t)pssbam::INF_WAVES_PER_CU;
     const uint32_t grid = std::min<uint32_t>(groups, (uint32_t)n_cu * per_cu);
+    // match-dominated batches (a BAM with constant or heavily binned QUAL inflates 8x and more) do best with short
+    // literal runs, literal-dominated ones with longer ones
+    uint32_t lit_run = out_bytes && out_bytes >= 8ull * comp_bytes ? 4u : 6u;
+    if (const char *lr = getenv("PSSBAM_INFLATE_RUN")) lit_run = (uint32_t)std::max(1, atoi(lr));
     if (loop > 0)
         hipLaunchKernelGGL(pssbam::bgzf_inflate_kernel<true>, dim3(grid), dim3(pssbam::INF_WAVE), pssbam::INF_LDS_BYTES_DEFER, st, (const uint8_t *)d_comp,
-                           comp_bytes, (pssbam::BgzfBlock *)d_blocks, n_blocks, (uint8_t *)d_out);
+                           comp_bytes, (pssbam::BgzfBlock *)d_blocks, n_blocks, (uint8_t *)d_out, lit_run);
     else
         hipLaunchKernelGGL(pssbam::bgzf_inflate_kernel<false>, dim3(grid), dim3(pssbam::INF_WAVE), pssbam::INF_LDS_BYTES, st, (const uint8_t *)d_comp,
-                           comp_bytes, (pssbam::BgzfBlock *)d_blocks, n_blocks, (uint8_t *)d_out);
+                           comp_bytes, (pssbam::BgzfBlock *)d_blocks, n_blocks, (uint8_t *)d_out, lit_run);
     HIP_TRY(hipGetLastError());
     if (check_crc) {
         uint32_t *xpow = nullptr;
@@ -123,7 +128,7 @@ static int launch_inflate(hipStream_t st, const void *d_comp, uint64_t comp_byte
 
 extern "C" int pssbam_bgzf_inflate_device(void *hip_stream, const void *d_comp, uint64_t comp_bytes, pssbam_bgzf_block *d_blocks,
                                           uint32_t n_blocks, void *d_out, int check_crc) {
-    return launch_inflate((hipStream_t)hip_stream, d_comp, comp_bytes, d_blocks, n_blocks, d_out, check_crc, -2);   // a caller's buffers: no over-reads
+    return launch_inflate((hipStream_t)hip_stream, d_comp, comp_bytes, d_blocks, n_blocks, d_out, check_crc, -2, 0);   // a caller's buffers: no over-reads
 }
 
 
@@ -170,7 +175,7 @@ extern "C" int pssbam_bgzf_inflate_host(int device, const void *bgzf, uint64_t n
     float best = 1e30f;
     for (int r = 0; r < repeats && rc == PSSBAM_OK; r++) {
         TRY_C(hipEventRecord(e0, nullptr));
-        rc = launch_inflate(nullptr, d_comp, nbytes, d_blocks, (uint32_t)n, d_out, check_crc, INFLATE_LOOP_DEFAULT);
+        rc = launch_inflate(nullptr, d_comp, nbytes, d_blocks, (uint32_t)n, d_out, check_crc, INFLATE_LOOP_DEFAULT, total);
         if (rc) break;
         TRY_C(hipEventRecord(e1, nullptr));
         TRY_C(hipEventSynchronize(e1));
@@ -327,7 +332,7 @@ static int feed_flush(pssbam_engine *e) {
     if (!ev0 || !ev1) return fail(PSSBAM_EHIP, "hipEventCreate failed");
     HIP_TRY(hipEventRecord(ev0, e->stream));
     rc = launch_inflate(e->stream, s.d_comp, s.comp_used, (pssbam_bgzf_block *)s.d_blocks, (uint32_t)nb, s.d_out, getenv("PSSBAM_NO_CRC") ? 0 : 1,
-                        INFLATE_LOOP_DEFAULT);
+                        INFLATE_LOOP_DEFAULT, data_end - FEED_GAP);
     if (rc) return rc;
     // the record chain of the whole super-batch: per-block pieces, linked and checked
     {

@@ -74,7 +74,9 @@ constexpr int INF_WAVES_PER_CU = 5;
 // loads does not help: the register allocator touches the loaded registers early and the wait moves there (measured:
 // slower than in place).  global_load_lds_dwordx4 from inline asm lands the data in LDS without the compiler knowing
 // a load is in flight; the one s_waitcnt vmcnt(0) of a step is written by hand, behind the decode phase.
-constexpr uint32_t INF_RUN_INPLACE = 4u, INF_RUN_DEFER = 8u;   // literals a lane may take per step (DEFER: they travel in one register)
+// literals a lane may take per step.  DEFER: they travel in one register (<= 8), and the budget is a launch
+// parameter -- 4 suits match-dominated streams, 6 literal-dominated ones (profiles/r02_inflate_variants.txt)
+constexpr uint32_t INF_RUN_INPLACE = 4u, INF_RUN_DEFER_MAX = 8u;
 // landing planes of the DEFER loop: three times 16 bytes per lane behind the decode tables (still five waves per CU)
 constexpr uint32_t INF_LAND_BYTES = 3u * 16u * INF_WAVE;
 constexpr uint32_t INF_LDS_BYTES_DEFER = INF_LDS_BYTES + INF_LAND_BYTES;
@@ -296,10 +298,10 @@ __device__ __forceinline__ void dma16_to_lds(uint32_t lds_base, const void *src)
                  : "=&s"(keep) : "v"(src), "s"(m0v) : "memory");
 }
 
-// One BGZF block by one lane.  Returns INF_*.  land: this wave's landing planes (DEFER only).
+// One BGZF block by one lane.  Returns INF_*.  land: this wave's landing planes, lit_run: literals per step (DEFER only).
 template <bool DEFER>
 __device__ uint32_t inflate_block(const uint8_t *comp, uint64_t comp_bytes, const BgzfBlock &b, uint8_t *outbuf, const LaneLds &t,
-                                  uint8_t *land, uint32_t lane) {
+                                  uint8_t *land, uint32_t lane, uint32_t lit_run) {
     uint8_t *out = outbuf + b.out_off;
     const uint32_t isize = b.isize;
     BitReader br;
@@ -475,7 +477,7 @@ __device__ uint32_t inflate_block(const uint8_t *comp, uint64_t comp_bytes, cons
                 int sym = 512;   // 512: no token this step
                 uint32_t run = 0;
                 uint64_t lits = 0;
-                while (run < INF_RUN_DEFER && br.avail() >= 64u) {   // (a token takes at most 48 bits)
+                while (run < lit_run && br.avail() >= 64u) {   // (a token takes at most 48 bits)
                     br.refill_nomem();
                     sym = huff_decode<15, true>(br, t, L_DELTA, L_SYM, 288, lu);
                     if (sym < 0 || sym >= 256) break;
@@ -668,7 +670,7 @@ __device__ uint32_t inflate_block(const uint8_t *comp, uint64_t comp_bytes, cons
 // grid of single-wave workgroups, each wave takes 64 consecutive blocks at a time
 template <bool DEFER>
 __global__ void __launch_bounds__(INF_WAVE) bgzf_inflate_kernel(const uint8_t *comp, uint64_t comp_bytes, BgzfBlock *blocks,
-                                                                uint32_t n_blocks, uint8_t *out) {
+                                                                uint32_t n_blocks, uint8_t *out, uint32_t lit_run) {
     extern __shared__ __attribute__((aligned(16))) uint8_t inf_lds[];
     const uint32_t lane = threadIdx.x;
     const LaneLds t{inf_lds + 4u * lane, inf_lds + INF_N16 * 2 * INF_WAVE + 4u * lane,
@@ -680,7 +682,7 @@ __global__ void __launch_bounds__(INF_WAVE) bgzf_inflate_kernel(const uint8_t *c
             uint32_t st = INF_OK;
             // (a descriptor the caller got wrong must not become a wild address)
             if (b.isize > 65536u || b.in_off > comp_bytes || b.in_len > comp_bytes - b.in_off) st = INF_BAD_BLOCK;
-            else if (b.isize) st = inflate_block<DEFER>(comp, comp_bytes, b, out, t, inf_lds + INF_LDS_BYTES, lane);
+            else if (b.isize) st = inflate_block<DEFER>(comp, comp_bytes, b, out, t, inf_lds + INF_LDS_BYTES, lane, min(max(lit_run, 1u), INF_RUN_DEFER_MAX));
             blocks[i].status = st;
         }
     }

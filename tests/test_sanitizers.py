@@ -89,3 +89,18 @@ def test_ragged_bam_digest_is_independent_of_batching(san, stress_files):
         outs.add(out)
     assert len(outs) == 1, outs
     assert _run(hc, ["-a", stress_files / "whole.bam"]) in outs      # same records, different BGZF layout
+
+
+def test_inflate_loop_schedule_in_the_compiled_kernel():
+    """the one-wait-per-step inflate loop only pays while the compiler keeps its hands off the stretch between the
+    LDS-DMA requests and the hand-written wait: tools/isa_inflate_check.py asserts that on hipcc's listing (a hipcc
+    update that changes it should fail here, not show up as a slower kernel)"""
+    import shutil
+    import subprocess
+    import sys
+    from pathlib import Path
+    if not Path("/opt/rocm/bin/hipcc").exists() and not shutil.which("hipcc"):
+        pytest.skip("no hipcc")
+    root = Path(__file__).resolve().parent.parent
+    pr = subprocess.run([sys.executable, str(root / "tools" / "isa_inflate_check.py")], capture_output=True, text=True, timeout=900)
+    assert pr.returncode == 0 and pr.stdout.startswith("ok:"), pr.stdout + pr.stderr
