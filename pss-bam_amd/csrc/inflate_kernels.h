@@ -742,6 +742,22 @@ __global__ void __launch_bounds__(1024) bgzf_crc_kernel(const uint8_t *out, Bgzf
         // time would fetch every line 32 times over
         uint32_t i = s;
         for (; i < e && ((uintptr_t)(p + i) & 15u); i++) crc = TAB(tab0, (crc ^ p[i]) & 0xFFu) ^ (crc >> 8);
+        // eight loads in flight per lane (a load at a time made the kernel a chain of memory round trips: 64 of them
+        // per chunk)
+        for (; i + 128u <= e; i += 128u) {
+            uint4 q[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) q[j] = *(const uint4 *)(p + i + 16u * (uint32_t)j);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const uint32_t d[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t w = d[k] ^ crc;
+                    crc = TAB(tab3, w & 0xFFu) ^ TAB(tab2, (w >> 8) & 0xFFu) ^ TAB(tab1, (w >> 16) & 0xFFu) ^ TAB(tab0, w >> 24);
+                }
+            }
+        }
         for (; i + 16u <= e; i += 16u) {
             const uint4 q = *(const uint4 *)(p + i);
             const uint32_t d[4] = {q.x, q.y, q.z, q.w};
