@@ -151,7 +151,7 @@ struct BitReader {
     // bits that can be handed out without touching memory
     __device__ __forceinline__ uint32_t avail() const { return cnt + 32u * rc + (n_valid ? 128u : 0u); }
     __device__ __forceinline__ void refill_nomem() {   // caller: avail() covers what it is about to take
-        if (cnt <= 32u) {
+        if (cnt <= 32u && (rc | n_valid)) {   // (nothing queued: the bits in buf are all there is until the next memory phase)
             if (rc == 0u) { r0 = n0; r1 = n1; rc = 4u; n_valid = 0u; }
             buf |= (r0 & 0xFFFFFFFFull) << cnt;
             cnt += 32u;
@@ -162,7 +162,7 @@ struct BitReader {
     }
     __device__ __forceinline__ void refill() {
         if (cnt <= 32u) {
-            if (rc == 0u) top_up();
+            if (rc == 0u) top_up();   // (n_valid afterwards)
             refill_nomem();
         }
     }
@@ -234,6 +234,28 @@ __device__ __forceinline__ int huff_decode(BitReader &br, const LaneLds &t, int 
     if (idx >= (uint32_t)n_sym) return -1;
     br.drop(L);
     return WIDE ? (int)t.get_litlen(idx) : (int)t.sym8(sym_at + (int)idx);
+}
+
+// The next TWO literal/length symbols, nothing dropped: b is decoded from the bits behind a's code before a's table
+// reads have come back, so the two LDS round trips of a symbol (offset of its code length, then the symbol) are
+// shared by the pair -- literal runs are what a BAM's quality strings inflate from.  sym < 0: no code of the table.
+struct LitPair { int a, b; uint32_t la, lb; };
+__device__ __forceinline__ LitPair litlen_peek2(const BitReader &br, const LaneLds &t, const uint32_t (&upper)[15]) {
+    const uint32_t ca = br.peek15();
+    uint32_t la = 1u;
+#pragma unroll
+    for (int k = 0; k < 15; k++) la += ca >= upper[k] ? 1u : 0u;
+    const uint32_t la_c = min(la, 15u);
+    const uint32_t cb = __brev((uint32_t)(br.buf >> la_c)) >> 17;   // (caller: at least 30 bits in buf)
+    uint32_t lb = 1u;
+#pragma unroll
+    for (int k = 0; k < 15; k++) lb += cb >= upper[k] ? 1u : 0u;
+    const uint32_t lb_c = min(lb, 15u);
+    const uint32_t da = t.at(L_DELTA + (int)la_c), db = t.at(L_DELTA + (int)lb_c);
+    const uint32_t ia = ((ca >> (15u - la_c)) + da) & 0xFFFFu, ib = ((cb >> (15u - lb_c)) + db) & 0xFFFFu;
+    const bool va = la <= 15u && ia < 288u, vb = lb <= 15u && ib < 288u;
+    const uint32_t sa = t.get_litlen(va ? ia : 0u), sb = t.get_litlen(vb ? ib : 0u);
+    return {va ? (int)sa : -1, vb ? (int)sb : -1, la_c, lb_c};
 }
 
 __device__ __forceinline__ uint64_t load_u64(const uint8_t *p) {
@@ -477,18 +499,26 @@ __device__ uint32_t inflate_block(const uint8_t *comp, uint64_t comp_bytes, cons
                 int sym = 512;   // 512: no token this step
                 uint32_t run = 0;
                 uint64_t lits = 0;
-                while (run < lit_run && br.avail() >= 64u) {   // (a token takes at most 48 bits)
+                while (run < lit_run && br.avail() >= 64u) {   // (two literals and a token take at most 30 + 33 bits)
                     br.refill_nomem();
-                    sym = huff_decode<15, true>(br, t, L_DELTA, L_SYM, 288, lu);
-                    if (sym < 0 || sym >= 256) break;
-                    lits |= (uint64_t)(uint32_t)sym << (8u * run);
+                    const LitPair lp = litlen_peek2(br, t, lu);
+                    if (lp.a < 0) { sym = -1; break; }
+                    br.drop(lp.la);
+                    if (lp.a >= 256) { sym = lp.a; break; }
+                    lits |= (uint64_t)(uint32_t)lp.a << (8u * run);
                     run++;
-                    sym = 512;
+                    if (lp.b >= 256) { br.drop(lp.lb); sym = lp.b; break; }   // the token behind the literal: decoded already
+                    if (lp.b >= 0 && run < INF_RUN_DEFER_MAX) {
+                        br.drop(lp.lb);
+                        lits |= (uint64_t)(uint32_t)lp.b << (8u * run);
+                        run++;
+                    }   // (lp.b < 0: the next round finds out)
                 }
                 if (sym < 0) return INF_BAD_SYMBOL;
                 uint32_t len = 0, dist = 0;
                 if (sym > 256 && sym != 512) {
                     if (sym > 285) return INF_BAD_SYMBOL;
+                    br.refill_nomem();
                     // length: 257..264 -> 3..10; 265..284 -> ((4 + (s-265)%4) << e) + 3 with e = (s-261)/4 extra bits; 285 -> 258
                     const uint32_t s = (uint32_t)sym;
                     if (s < 265u) len = s - 254u;
@@ -669,7 +699,7 @@ __device__ uint32_t inflate_block(const uint8_t *comp, uint64_t comp_bytes, cons
 
 // grid of single-wave workgroups, each wave takes 64 consecutive blocks at a time
 template <bool DEFER>
-__global__ void __launch_bounds__(INF_WAVE) bgzf_inflate_kernel(const uint8_t *comp, uint64_t comp_bytes, BgzfBlock *blocks,
+__global__ void __launch_bounds__(INF_WAVE) __attribute__((amdgpu_waves_per_eu(2))) bgzf_inflate_kernel(const uint8_t *comp, uint64_t comp_bytes, BgzfBlock *blocks,
                                                                 uint32_t n_blocks, uint8_t *out, uint32_t lit_run) {
     extern __shared__ __attribute__((aligned(16))) uint8_t inf_lds[];
     const uint32_t lane = threadIdx.x;
