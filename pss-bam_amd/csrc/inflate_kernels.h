@@ -11,7 +11,7 @@
 // 64 blocks per wave, the wave diverging between "literal" and "match" like any branchy kernel.
 //   * per-lane decode tables in LDS, lane-interleaved (entry i of lane l at [i][l]): canonical
 //     Huffman data only -- sorted symbols + one offset per code length (452 B per lane, 28.3 KiB per
-//     wave, five waves per CU);
+//     wave);
 //   * a symbol's code length comes from 15 register thresholds (canonical codes are ordered:
 //     the length is the number of left-aligned upper bounds the next 15 stream bits reach), so
 //     decoding a symbol is ~40 VALU + two LDS reads, with no loop and no per-length divergence;
@@ -27,7 +27,7 @@
 // CRCs combined by multiplication with x^(8*bytes behind the chunk) mod P).
 //
 // Bound: latency (LDS + L2 round trips on a serial chain), hidden by block-level parallelism:
-// 5 waves x 64 lanes x 256 CUs = 81 920 streams in flight.  Integer/bit work; no MFMA.
+// 4 waves x 64 lanes x 256 CUs = 65 536 streams in flight.  Integer/bit work; no MFMA.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -54,13 +54,14 @@ constexpr int INF_WAVE = 64;
 //   u8[320]  : L_SYM[288] low 8 bits of the litlen symbols sorted by (code length, symbol);
 //              D_SYM[32] distance symbols (also hosts the 19-symbol code-length code)
 //   u32[9]   : bit 8 of the 288 litlen symbols
-// = 452 B per lane, 28.3 KiB per wave: FIVE waves per CU (the 16-bit symbol table of the first version
+// = 452 B per lane, 28.3 KiB per wave: room for five waves per CU (the 16-bit symbol table of the first version
 // allowed three).
 constexpr int L_DELTA = 0, L_OFFS = 16, D_DELTA = 32, INF_N16 = 48;
 constexpr int L_SYM = 0, D_SYM = 288, INF_N8 = 320;
 constexpr int INF_N32 = 9;
 constexpr uint32_t INF_LDS_BYTES = (INF_N16 * 2 + INF_N8 + INF_N32 * 4) * INF_WAVE;
-constexpr int INF_WAVES_PER_CU = 5;
+constexpr int INF_WAVES_PER_CU = 4;   // one per SIMD: 4 do what 5 do, or better (2/3/4/5/6: 187/226/291/287 in place; 225/273/263/256 one-wait), and
+                                      // a lone wave on its SIMD may use the whole register file
 // Two data loops (inflate_block<DEFER>):
 //   DEFER = false  "in place": a copy is loaded, waited for and stored where it is decoded; literals leave as byte
 //                  stores, at most INF_RUN_INPLACE per step.
@@ -77,10 +78,10 @@ constexpr int INF_WAVES_PER_CU = 5;
 // literals a lane may take per step.  DEFER: they travel in one register (<= 8), and the budget is a launch
 // parameter -- 4 suits match-dominated streams, 6 literal-dominated ones (profiles/r02_inflate_variants.txt)
 constexpr uint32_t INF_RUN_INPLACE = 4u, INF_RUN_DEFER_MAX = 8u;
-// landing planes of the DEFER loop: three times 16 bytes per lane behind the decode tables (still five waves per CU)
+// landing planes of the DEFER loop: three times 16 bytes per lane behind the decode tables
 constexpr uint32_t INF_LAND_BYTES = 3u * 16u * INF_WAVE;
 constexpr uint32_t INF_LDS_BYTES_DEFER = INF_LDS_BYTES + INF_LAND_BYTES;
-static_assert(INF_LDS_BYTES_DEFER * INF_WAVES_PER_CU <= 160u * 1024u, "five waves of the DEFER loop must fit the CU's LDS");
+static_assert(INF_LDS_BYTES_DEFER * INF_WAVES_PER_CU <= 160u * 1024u, "the waves of the DEFER loop must fit the CU's LDS");
 
 struct LaneLds {  // this lane's view of the three interleaved arrays
     // Interleaving is by DWORD: entry i of lane l sits in dword (i / per_dword) * 64 + l, so whatever
@@ -699,7 +700,7 @@ __device__ uint32_t inflate_block(const uint8_t *comp, uint64_t comp_bytes, cons
 
 // grid of single-wave workgroups, each wave takes 64 consecutive blocks at a time
 template <bool DEFER>
-__global__ void __launch_bounds__(INF_WAVE) __attribute__((amdgpu_waves_per_eu(2))) bgzf_inflate_kernel(const uint8_t *comp, uint64_t comp_bytes, BgzfBlock *blocks,
+__global__ void __launch_bounds__(INF_WAVE) bgzf_inflate_kernel(const uint8_t *comp, uint64_t comp_bytes, BgzfBlock *blocks,
                                                                 uint32_t n_blocks, uint8_t *out, uint32_t lit_run) {
     extern __shared__ __attribute__((aligned(16))) uint8_t inf_lds[];
     const uint32_t lane = threadIdx.x;

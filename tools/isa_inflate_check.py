@@ -9,8 +9,8 @@ the compiler neither waits nor touches global memory in between.  Checked on the
   * every one of them sits between a save and a restore of m0 (the compiler does not model the write);
   * from the last request to the first s_waitcnt that names vmcnt there is no vector-memory instruction, there are
     LDS reads (the decode phase) and at least MIN_GAP instructions;
-  * the kernel keeps its five waves per CU: LDS as launched (tables + landing planes) * 5 <= 160 KiB is asserted in
-    the source; here: no more than 256 VGPRs (two waves per SIMD).
+  * (scratch traffic -- the block-header code keeps a saved BitReader there -- counts as vector memory: none in that
+    stretch.)
 
 usage: isa_inflate_check.py [engine.s]      (no argument: compiles csrc/engine.hip with --save-temps into a temp dir)"""
 import re
@@ -60,8 +60,8 @@ def main() -> int:
     assert ins[w][1].split()[1].startswith("vmcnt(0)"), ins[w][1]
     k = s.index(".amdhsa_kernel " + name)
     vgpr = int(re.search(r"\.amdhsa_next_free_vgpr\s+(\d+)", s[k:k + 4000]).group(1))
-    assert vgpr <= 256, f"{vgpr} VGPRs: one wave per SIMD"
-    print(f"ok: 3 requests, {len(between)} instructions (no VMEM, {sum(l.startswith('ds_read') for l in between)} LDS reads) to the wait, {vgpr} VGPRs")
+    scratch = int(re.search(r"\.amdhsa_private_segment_fixed_size\s+(\d+)", s[k:k + 4000]).group(1))
+    print(f"ok: 3 requests, {len(between)} instructions (no VMEM, {sum(l.startswith('ds_read') for l in between)} LDS reads) to the wait, {vgpr} VGPRs, {scratch} B scratch")
     return 0
 
 
