@@ -511,9 +511,36 @@ def e2e_leg(pkg, synth, cd, region_len, n_reads, resident_reads, resident_counte
             want_r = resident_counters[lay["rev"]:lay["rev"] + rows * 16].reshape(rows, 16)
             ok = bool(np.array_equal(got_f, want_f) and np.array_equal(got_r, want_r))
             check = "tables identical to the HBM-resident tally of the same slots" if ok else "MISMATCH vs the resident tally"
+        # The named configurations have constant QUAL, which DEFLATE turns into one long match per read.
+        # A second, smaller file with 40-level quality strings at level 6 shows the same command on what a
+        # sequencer's BAM looks like to the feed: ~4x the compressed bytes per read, a literal-heavy stream.
+        real = None
+        bam_bytes = bam.stat().st_size
+        n_real = min(n_reads, int(os.environ.get("PSSBAM_E2E_REAL_READS", "50000000")))
+        if n_real > 0:
+            try:
+                bam.unlink()
+                t = time.perf_counter()
+                synth.bam_file_host(cfg, 0, n_real, bam, level=6, threads=threads, quals="full")
+                t_bam2 = time.perf_counter() - t
+                r_h = run_cli({"PSSBAM_DEVICE_INFLATE": "0"}, "real_host")
+                rr = sorted((run_cli({}, "real") for _ in range(3)), key=lambda r: r[1])
+                if all(r[0].returncode == 0 for r in rr) and r_h[0].returncode == 0:
+                    same = all(np.array_equal(a, b) for a, b in zip(tl.parse_counts_text((tmp / "real_host.pss.counts.txt").read_text()),
+                                                                     tl.parse_counts_text((tmp / "real.pss.counts.txt").read_text())))
+                    mm = re.search(r"device feed: (.*)\n", rr[1][0].stderr)
+                    real = {"what": "the same command on a BAM with 40-level quality strings, deflate level 6 (synth.bam_file_host quals='full')",
+                            "reads": n_real, "bam_bytes": bam.stat().st_size, "wall_s": rr[1][1], "reads_per_s": n_real / rr[1][1],
+                            "wall_s_runs": [r[1] for r in rr], "wall_s_is": "median of 3 runs", "device_feed": mm.group(1) if mm else None,
+                            "host_inflate_run": {"wall_s": r_h[1], "reads_per_s": n_real / r_h[1], "tables_identical": bool(same)},
+                            "workload_gen_s": t_bam2}
+                else:
+                    real = {"error": (rr[0][0].stderr or r_h[0].stderr)[-500:]}
+            except Exception as ex:   # the headline e2e object must not depend on this one
+                real = {"error": repr(ex)}
         return {
             "command": "bin/pss-bam -F ref.fa -B reads.bam -o out -r %d" % region_len,
-            "reads": n_reads, "bam_bytes": bam.stat().st_size, "fasta_bytes": fa.stat().st_size,
+            "reads": n_reads, "bam_bytes": bam_bytes, "fasta_bytes": fa.stat().st_size,
             "deflate_level": 1, "block_layout": "htslib", "host_cpus_effective": effective_cpus(),
             "wall_s": wall, "reads_per_s": n_reads / wall, "wall_s_runs": [r[1] for r in runs], "wall_s_is": "median of 3 runs",
             "tally_phase_s": tally_s, "reads_per_s_tally_phase": n_reads / tally_s if tally_s else None,
@@ -527,6 +554,7 @@ def e2e_leg(pkg, synth, cd, region_len, n_reads, resident_reads, resident_counte
                                  if pr_h.returncode == 0 else {"error": pr_h.stderr[-500:]}),
             "tables_check": check, "note": note,
             "workload_gen_s": {"fasta": t_fa, "bam": t_bam},
+            "real_quals": real,
         }
     finally:
         shutil.rmtree(tmp, ignore_errors=True)

@@ -54,4 +54,8 @@ def test_bench_e2e_leg_small():
     e = d["e2e"]
     assert "error" not in e, e
     assert e["reads"] == 3_000_000 and e["tables_check"].startswith("tables identical")
-    assert e["wall_s"] > 0 and e["fasta_load_s"] is not None
+    assert e["wall_s"] > 0 and e["fasta_load_s"] is not None and len(e["wall_s_runs"]) == 3
+    assert e["host_inflate_run"]["tables_identical"]
+    r = e["real_quals"]   # the same command on a BAM with sequencer-like quality strings
+    assert "error" not in r, r
+    assert r["reads"] == 3_000_000 and r["host_inflate_run"]["tables_identical"] and r["bam_bytes"] > 2 * e["bam_bytes"]
