@@ -322,7 +322,22 @@ static int feed_flush(pssbam_engine *e) {
     HIP_TRY(hipEventRecord(s.copies_done2, e->copy_stream2));
     HIP_TRY(hipStreamWaitEvent(e->stream, s.copies_done, 0));
     HIP_TRY(hipStreamWaitEvent(e->stream, s.copies_done2, 0));
-    HIP_TRY(hipMemcpyAsync(s.d_blocks, s.blocks.data(), nb * sizeof(pssbam_bgzf_block), hipMemcpyHostToDevice, e->stream));
+    // the table goes up from page-locked memory: a pageable source makes hipMemcpyAsync wait for everything queued on
+    // the stream (the previous super-batch's kernels), and this thread has the next super-batch's copies to issue
+    if (s.h_blocks_cap < nb) {
+        if (s.h_blocks) (void)hipHostFree(s.h_blocks);
+        s.h_blocks = nullptr;
+        s.h_blocks_cap = 0;
+        const size_t cap = std::max<size_t>(nb + nb / 4, 1u << 16);
+        if (hipHostMalloc((void **)&s.h_blocks, cap * sizeof(pssbam_bgzf_block), hipHostMallocDefault) == hipSuccess) s.h_blocks_cap = cap;
+        else s.h_blocks = nullptr;   // (pageable then: slower, not wrong)
+    }
+    const pssbam_bgzf_block *table = s.blocks.data();
+    if (s.h_blocks) {
+        memcpy(s.h_blocks, s.blocks.data(), nb * sizeof(pssbam_bgzf_block));
+        table = s.h_blocks;
+    }
+    HIP_TRY(hipMemcpyAsync(s.d_blocks, table, nb * sizeof(pssbam_bgzf_block), hipMemcpyHostToDevice, e->stream));
     if (e->feed_fresh) {   // the stream's first super-batch: its chain starts behind the BAM header
         const uint64_t first = FEED_GAP + e->feed_skip;
         HIP_TRY(hipMemcpyAsync(s.d_chain, &first, sizeof first, hipMemcpyHostToDevice, e->stream));   // (pageable source: copied before the call returns)

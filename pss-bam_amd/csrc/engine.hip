@@ -91,6 +91,8 @@ struct FeedAcc {  // one super-batch of compressed blocks: assembled chunk by ch
     std::vector<uint32_t> sub_first;         // first block of every tally sub-batch (< 4 GiB of records each)
     uint64_t out_used = 0, sub_bytes = 0;
     void *d_blocks = nullptr;                // pssbam::BgzfBlock[]
+    pssbam_bgzf_block *h_blocks = nullptr;   // page-locked copy of `blocks` for the upload (a pageable source makes hipMemcpyAsync wait for the stream)
+    size_t h_blocks_cap = 0;
     // per block: chain pieces (first record start, records, end, last record start), suffix minimum, counts, bases
     uint64_t *d_a = nullptr, *d_e = nullptr, *d_last = nullptr, *d_nexta = nullptr;
     uint32_t *d_n = nullptr, *d_counts = nullptr, *d_base = nullptr;
@@ -291,6 +293,7 @@ extern "C" void pssbam_engine_destroy(pssbam_engine *e) {
         void *ptrs[] = {s.d_comp, s.d_blocks, s.d_a, s.d_e, s.d_last, s.d_nexta, s.d_n, s.d_counts, s.d_base, s.d_out, s.d_offs, s.d_nrecs, s.d_chain};
         for (void *q : ptrs)
             if (q) (void)hipFree(q);
+        if (s.h_blocks) (void)hipHostFree(s.h_blocks);
         if (s.consumed) (void)hipEventDestroy(s.consumed);
         if (s.copies_done) (void)hipEventDestroy(s.copies_done);
         if (s.copies_done2) (void)hipEventDestroy(s.copies_done2);
