@@ -881,9 +881,15 @@ __global__ void __launch_bounds__(256) bgzf_chain_spec(const uint8_t *out, const
                 // (the bytes behind the block's end are the next block's: the buffer is contiguous, so a record
                 //  that starts in the last bytes of the block can be judged too; a candidate must also
                 //  survive two records beyond the block -- with small blocks its own record says little)
+                // Scan and walk are separate loops on purpose: the lanes of a wave find their candidates at
+                // different offsets, and with the walk nested inside the scan every lane walked its block ALONE
+                // while the others waited for the scan to come round to them (18 ms per super-batch of a file
+                // whose records cross blocks; 1.5 ms with htslib's layout, where every candidate is offset 0).
                 uint32_t tries = 0;
-                for (uint64_t c = lo; c < hi && tries < 4u; c++) {
-                    if (!plausible_record(out + c, data_end - c, n_ref)) continue;
+                uint64_t c = lo;
+                while (tries < 4u) {
+                    while (c < hi && !plausible_record(out + c, data_end - c, n_ref)) c++;
+                    if (c >= hi) break;
                     tries++;
                     uint64_t o = c, l = c, end_in = c;
                     uint32_t k = 0, extra = 0;
@@ -900,6 +906,7 @@ __global__ void __launch_bounds__(256) bgzf_chain_spec(const uint8_t *out, const
                         if (o >= data_end) break;
                     }
                     if (good && k) { a_b = c; n_b = k; e_b = end_in; last_b = l; break; }
+                    c++;
                 }
             }
         }

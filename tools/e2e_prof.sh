@@ -12,7 +12,8 @@ d = synth.config("C3"); d.pop("region_len")
 cfg = synth.make_cfg(**d)
 n = int(os.environ.get("E2E_READS", "200000000"))
 synth.fasta_host(cfg, "/tmp/e2e_in/ref.fa", threads=bench.worker_threads())
-synth.bam_file_host(cfg, 0, n, "/tmp/e2e_in/reads.bam", level=1, threads=bench.worker_threads())
+synth.bam_file_host(cfg, 0, n, "/tmp/e2e_in/reads.bam", level=int(os.environ.get("E2E_LEVEL", "1")), threads=bench.worker_threads(),
+                    ragged=bool(int(os.environ.get("E2E_RAGGED", "0"))), quals=os.environ.get("E2E_QUALS", "const"))
 PY
 PSSBAM_CLEAN_EXIT=1 PSSBAM_STATS=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- pss-bam_amd/bin/pss-bam -F /tmp/e2e_in/ref.fa -B /tmp/e2e_in/reads.bam -o /tmp/e2e_in/out -r 25 > $OUT/run.log 2>&1
 grep -E "device feed|phases|gpus=" $OUT/run.log
