@@ -17,10 +17,12 @@
 //     decoding a symbol is ~40 VALU + two LDS reads, with no loop and no per-length divergence;
 //   * the dynamic block header is parsed twice (count, then place) instead of storing 320 code
 //     lengths per lane;
-//   * 64-bit bit buffer refilled by aligned dword loads; matches with distance >= 8 move 8 bytes
-//     per step, shorter distances are expanded from a periodic 8-byte register pattern (the
-//     QUAL runs of a BAM are distance-1 matches: no load-after-store chain);
-//   * every access is bounded: reads inside the block's payload (+ one dword of slack the caller
+//   * 64-bit bit buffer fed 16 stream bytes per request; far copies move 16/32 bytes at a time, distances < 8
+//     are expanded from a periodic register pattern (the QUAL runs of a BAM are distance-1 matches: no
+//     load-after-store chain);
+//   * two data loops (inflate_block<DEFER>, below): the engine feed runs the one that requests a step's
+//     loads by LDS-DMA and waits once per step, behind the decode work;
+//   * every access is bounded: reads inside the compressed buffer (+ one dword of slack the caller
 //     provides), writes inside [out_off, out_off + isize); a malformed stream sets the block's
 //     status and stops that lane.
 // A second kernel checks ISIZE/CRC-32 per block (wave per block, 1 KiB chunks per lane, chunk
