@@ -403,3 +403,39 @@ def test_cli_device_feed_edge_files(pkg, tmp_path):
     cut_rec.write_bytes(b"".join(tl.bgzf_block(part[i:i + 0xFF00], 6) for i in range(0, len(part), 0xFF00)) + tl.BGZF_EOF)
     pr = run(cut_rec, "c2")
     assert pr.returncode != 0 and "truncated" in pr.stderr.lower(), pr.stderr[-1500:]
+
+
+def test_cli_damaged_record_stream_same_outcome_in_both_feeds(pkg, tmp_path):
+    """random overwrites in the RECORD stream, BGZF-compressed afterwards (every CRC is right): the device-side
+    record chain meets broken block_size fields and cut-off records.  The command may fail with a diagnosis or
+    fall back to the host reader -- the outcome must be the host reader's (same tables, or a failure in both),
+    never a signal (tools/feed_soak.py is the long version)"""
+    import os
+    import subprocess
+    contigs, refs, recs = tl.fuzz_dataset(123, 3000)
+    fa = tmp_path / "g.fa"
+    tl.write_fasta(fa, contigs)
+    good = tmp_path / "good.bam"
+    tl.write_bam_aligned(good, refs, recs, level=6)
+    data = bytearray(tl.bgzf_inflate(good.read_bytes()))
+    header_end = _bam_header_bytes(good.read_bytes())
+    rng = np.random.default_rng(9)
+    b = pkg.PKG_DIR / "bin" / "pss-bam"
+    for f in range(6):
+        d = bytearray(data)
+        for _ in range(int(rng.integers(1, 5))):
+            at = int(rng.integers(header_end, len(d) - 8))
+            m = int(rng.integers(1, 6))
+            d[at:at + m] = bytes(rng.integers(0, 256, m, dtype=np.uint8))
+        blk = [300, 5000, 0xFF00][f % 3]
+        bam = tmp_path / "bad.bam"
+        bam.write_bytes(b"".join(tl.bgzf_block(bytes(d[i:i + blk]), 6) for i in range(0, len(d), blk)) + tl.BGZF_EOF)
+        res = []
+        for tag, env in (("d", {}), ("h", {"PSSBAM_DEVICE_INFLATE": "0"})):
+            pr = subprocess.run([str(b), "-F", str(fa), "-B", str(bam), "-o", str(tmp_path / tag), "-r", "10"],
+                                capture_output=True, text=True, env={**os.environ, **env}, timeout=120)
+            assert pr.returncode >= 0, (f, tag, pr.returncode, pr.stderr[-400:])
+            res.append(pr.returncode)
+        assert (res[0] == 0) == (res[1] == 0), (f, res)
+        if res[0] == 0:
+            assert (tmp_path / "d.pss.counts.txt").read_text().split("\n", 6)[-1] == (tmp_path / "h.pss.counts.txt").read_text().split("\n", 6)[-1], f
