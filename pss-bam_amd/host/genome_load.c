@@ -27,6 +27,7 @@
  *   file starts with '>' ; every header line ends in '\n' ; ids <= MAX_ID_LEN.
  */
 #include "fasta-genome-io.h"
+#include "inflate_fast.h"
 
 #include <errno.h>
 #include <fcntl.h>
@@ -361,15 +362,23 @@ static void fa_run(fa_job *job, int pass, int n_threads)
     for (int t = 0; t < started; t++) pthread_join(th[t], NULL);
 }
 
-/* Returns 1 = loaded into *out (NULL there = malformed input, already reported),
- * 0 = not applicable, use the one-thread parser. */
-static int load_parallel(const char fn[], Genome **out)
+static int fasta_threads(void)
 {
     int n_threads = 16;
     const char *ev = getenv("PSSBAM_FASTA_THREADS");
     long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
     if (ev) n_threads = atoi(ev);
     if (ncpu > 0 && n_threads > ncpu) n_threads = (int)ncpu;
+    return n_threads;
+}
+
+static int parse_parallel(const unsigned char *data, size_t size, const char fn[], int n_threads, Genome **out);
+
+/* Returns 1 = loaded into *out (NULL there = malformed input, already reported),
+ * 0 = not applicable, use the one-thread parser. */
+static int load_parallel(const char fn[], Genome **out)
+{
+    const int n_threads = fasta_threads();
     if (n_threads < 2) return 0;
 
     int fd = open(fn, O_RDONLY);
@@ -381,7 +390,14 @@ static int load_parallel(const char fn[], Genome **out)
     close(fd);
     if (data == (const unsigned char *)MAP_FAILED) return 0;
     (void)madvise((void *)data, size, MADV_SEQUENTIAL);
+    const int rc = parse_parallel(data, size, fn, n_threads, out);
+    munmap((void *)data, size);
+    return rc;
+}
 
+/* the text of a whole FASTA file in memory -> contigs (same return convention) */
+static int parse_parallel(const unsigned char *data, size_t size, const char fn[], int n_threads, Genome **out)
+{
     int applicable = 1, bad = 0;
     Genome *genome = NULL;
     fa_job job;
@@ -457,7 +473,6 @@ out:
     for (size_t k = 0; k < job.n_pc; k++) free(job.pc[k].seg);
     free(job.pc);
     pthread_mutex_destroy(&job.mu);
-    munmap((void *)data, size);
     if (!applicable) {
         if (genome) destroy_genome(genome);
         return 0;
@@ -474,6 +489,121 @@ out:
     return 1;
 }
 
+/* ------------------------------------------------------------------------------------ */
+/* .gz files written by bgzip (BGZF: what `samtools faidx` wants a compressed reference   */
+/* to be): independent <= 64 KiB deflate blocks, inflated by all threads at once          */
+/* ------------------------------------------------------------------------------------ */
+typedef struct { size_t in_off; uint32_t in_len, isize, crc; size_t out_off; } fa_bgzf_block;
+
+typedef struct {
+    const unsigned char *data;
+    unsigned char *text;
+    const fa_bgzf_block *blk;
+    size_t n_blk, next;
+    pthread_mutex_t mu;
+    int bad;
+} fa_bgzf_job;
+
+static void *fa_bgzf_worker(void *arg)
+{
+    fa_bgzf_job *job = (fa_bgzf_job *)arg;
+    pss_inflater *st = (pss_inflater *)malloc(sizeof *st);
+    if (!st) { job->bad = 1; return NULL; }
+    for (;;) {
+        pthread_mutex_lock(&job->mu);
+        const size_t k0 = job->next;
+        job->next += 64;
+        pthread_mutex_unlock(&job->mu);
+        if (k0 >= job->n_blk || job->bad) break;
+        for (size_t k = k0; k < k0 + 64 && k < job->n_blk; k++) {
+            const fa_bgzf_block *b = &job->blk[k];
+            if (!b->isize) continue;
+            if (pss_inflate_raw(st, job->data + b->in_off, b->in_len, job->text + b->out_off, b->isize) != 0 ||
+                pss_crc32(0, job->text + b->out_off, b->isize) != b->crc) { job->bad = 1; break; }
+        }
+    }
+    free(st);
+    return NULL;
+}
+
+/* 1 = handled (*out set, NULL = malformed and reported), 0 = not a BGZF file / not applicable: gzread copes */
+static int load_bgzf_parallel(const char fn[], Genome **out)
+{
+    const int n_threads = fasta_threads();
+    if (n_threads < 2) return 0;
+    int fd = open(fn, O_RDONLY);
+    struct stat sb;
+    if (fd < 0) return 0;
+    if (fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode) || sb.st_size < 28) { close(fd); return 0; }
+    const size_t size = (size_t)sb.st_size;
+    const unsigned char *data = (const unsigned char *)mmap(NULL, size, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (data == (const unsigned char *)MAP_FAILED) return 0;
+    int rc = 0;
+    fa_bgzf_block *blk = NULL;
+    size_t n_blk = 0, cap = 0, total = 0, o = 0;
+    unsigned char *text = NULL;
+    /* every gzip member must be a BGZF block: FEXTRA with a 'B','C' subfield of two bytes (SAM spec 4.1) */
+    while (o < size) {
+        if (size - o < 18 || data[o] != 0x1f || data[o + 1] != 0x8b || data[o + 2] != 8 || !(data[o + 3] & 4)) goto done;
+        const size_t xlen = (size_t)data[o + 10] | ((size_t)data[o + 11] << 8);
+        if (size - o < 12 + xlen + 8) goto done;
+        size_t bsize = 0, x = o + 12;
+        while (x + 4 <= o + 12 + xlen) {
+            const size_t sl = (size_t)data[x + 2] | ((size_t)data[x + 3] << 8);
+            if (data[x] == 'B' && data[x + 1] == 'C' && sl == 2 && x + 6 <= o + 12 + xlen) bsize = ((size_t)data[x + 4] | ((size_t)data[x + 5] << 8)) + 1;
+            x += 4 + sl;
+        }
+        if (!bsize || bsize < 12 + xlen + 8 || bsize > size - o || (data[o + 3] & ~4)) goto done; /* (other header flags: not what bgzip writes) */
+        if (n_blk == cap) {
+            cap = cap ? cap * 2 : 4096;
+            fa_bgzf_block *nb = (fa_bgzf_block *)realloc(blk, cap * sizeof *nb);
+            if (!nb) goto done;
+            blk = nb;
+        }
+        fa_bgzf_block *b = &blk[n_blk++];
+        b->in_off = o + 12 + xlen;
+        b->in_len = (uint32_t)(bsize - 12 - xlen - 8);
+        memcpy(&b->crc, data + o + bsize - 8, 4);
+        memcpy(&b->isize, data + o + bsize - 4, 4);
+        if (b->isize > 65536u) goto done;
+        b->out_off = total;
+        total += b->isize;
+        o += bsize;
+    }
+    if (total < ((size_t)1 << 20)) goto done; /* small: the serial reader is as good */
+    text = (unsigned char *)contig_alloc(total + 1);
+    if (!text) goto done;
+    {
+        fa_bgzf_job job;
+        memset(&job, 0, sizeof job);
+        job.data = data;
+        job.text = text;
+        job.blk = blk;
+        job.n_blk = n_blk;
+        pthread_mutex_init(&job.mu, NULL);
+        pthread_t th[64];
+        int started = 0;
+        for (int t = 0; t < n_threads - 1 && t < 64; t++)
+            if (pthread_create(&th[started], NULL, fa_bgzf_worker, &job) == 0) started++;
+        fa_bgzf_worker(&job);
+        for (int t = 0; t < started; t++) pthread_join(th[t], NULL);
+        pthread_mutex_destroy(&job.mu);
+        if (job.bad) {
+            fprintf(stderr, "%s: damaged BGZF block (inflate / CRC-32 check failed)\n", fn);
+            *out = NULL;
+            rc = 1;
+            goto done;
+        }
+    }
+    rc = parse_parallel(text, total, fn, n_threads, out);
+done:
+    free(text); /* (contig_alloc memory is free()-able) */
+    free(blk);
+    munmap((void *)data, size);
+    return rc;
+}
+
 Genome *init_genome(const char fn[])
 {
     Genome *genome;
@@ -488,6 +618,7 @@ Genome *init_genome(const char fn[])
     memset(&src, 0, sizeof src);
     src.gz = is_gz(fn);
     if (!src.gz && load_parallel(fn, &genome)) return genome;
+    if (src.gz && load_bgzf_parallel(fn, &genome)) return genome;
     if (src.gz) {
         src.zf = gzopen(fn, "rb");
         if (!src.zf) {

@@ -143,6 +143,38 @@ def test_genome_loader_parallel_equals_serial(host, tmp_path, oracle):  # noqa: 
     assert not L.init_genome(str(pre).encode())
 
 
+def test_genome_loader_bgzf_fasta(host, tmp_path):
+    """a .gz reference written by bgzip (BGZF blocks: what `samtools faidx` needs) is inflated by all threads at
+    once and parsed like a plain file; plain gzip keeps going through gzread; a damaged block is diagnosed"""
+    import gzip
+    L, _ = host
+    rng = np.random.default_rng(21)
+    contigs = [("chr2", tl.random_contig(rng, 1_400_000)), ("chr1", tl.random_contig(rng, 900_000)), ("tiny", "acgtn"), ("e", "")]
+    plain = tmp_path / "ref.fa"
+    tl.write_fasta(plain, contigs, width=60)
+    raw = plain.read_bytes()
+    assert len(raw) > (2 << 20)
+    want = sorted((cid, seq.upper().encode()) for cid, seq in contigs)
+    bg = tmp_path / "ref.bgzf.fa.gz"
+    bg.write_bytes(b"".join(tl.bgzf_block(raw[i:i + 0xFF00], 6) for i in range(0, len(raw), 0xFF00)) + tl.BGZF_EOF)
+    gz = tmp_path / "ref.plain.fa.gz"
+    gz.write_bytes(gzip.compress(raw, 1))
+    for path in (bg, gz):
+        for threads in ("16", "3", "1"):
+            os.environ["PSSBAM_FASTA_THREADS"] = threads
+            try:
+                g, got = _genome_contents(L, path)
+            finally:
+                del os.environ["PSSBAM_FASTA_THREADS"]
+            assert [(a, b) for a, b, _ in got] == want, (path.name, threads)
+            L.destroy_genome(g)
+    bad = bytearray(bg.read_bytes())
+    bad[len(bad) // 2] ^= 0x10
+    dmg = tmp_path / "damaged.fa.gz"
+    dmg.write_bytes(bytes(bad))
+    assert not L.init_genome(str(dmg).encode())
+
+
 def test_genome_loader_equals_oracle_on_golden(host, oracle):
     L, _ = host
     for ds in MANIFEST["datasets"].values():
