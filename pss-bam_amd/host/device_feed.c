@@ -263,7 +263,7 @@ int run_device_feed(pssbam_engine *const *eng, int n_gpus, const char *path, siz
             return -1;
         }
     }
-#define L (F->L)
+    loader_t *const L = &F->L;
     const int n_th = F->n_th, max_inflight = F->max_inflight;
     size_t out_cap = env_size("PSSBAM_FEED_BATCH_BYTES", (size_t)768 << 20); /* inflated bytes per submit */
     if (out_cap > ((size_t)1 << 30)) out_cap = (size_t)1 << 30;
@@ -291,13 +291,13 @@ int run_device_feed(pssbam_engine *const *eng, int n_gpus, const char *path, siz
         const double tr_ = mono_s();                                                                     \
         if (pssbam_engine_wait_bgzf_copied(eng[fifo[q].g], fifo[q].ticket)) goto done;                    \
         t_wait_copy += mono_s() - tr_;                                                                   \
-        stage_t *rs = &L.st[fifo[q].chunk % L.n_st];                                                      \
-        if (--pending_of_chunk[fifo[q].chunk % L.n_st] == 0) {                                            \
-            pthread_mutex_lock(&L.mu);                                                                    \
-            rs->free_for = fifo[q].chunk + L.n_st;                                                        \
+        stage_t *rs = &L->st[fifo[q].chunk % L->n_st];                                                      \
+        if (--pending_of_chunk[fifo[q].chunk % L->n_st] == 0) {                                            \
+            pthread_mutex_lock(&L->mu);                                                                    \
+            rs->free_for = fifo[q].chunk + L->n_st;                                                        \
             rs->loaded = -1;                                                                              \
-            pthread_cond_broadcast(&L.cv);                                                                \
-            pthread_mutex_unlock(&L.mu);                                                                  \
+            pthread_cond_broadcast(&L->cv);                                                                \
+            pthread_mutex_unlock(&L->mu);                                                                  \
         }                                                                                                 \
         fifo_head = (fifo_head + 1) % 128;                                                                \
         fifo_len--;                                                                                       \
@@ -309,17 +309,17 @@ int run_device_feed(pssbam_engine *const *eng, int n_gpus, const char *path, siz
     size_t skip = header_bytes;    /* inflated bytes still to skip in front of the first record */
     uint64_t n_submits = 0;
     int last_g = -1;
-    for (long k = 0; k < L.n_chunks; k++) {
-        stage_t *s = &L.st[k % L.n_st];
+    for (long k = 0; k < L->n_chunks; k++) {
+        stage_t *s = &L->st[k % L->n_st];
         const double tw = mono_s();
-        pthread_mutex_lock(&L.mu);
-        while (s->loaded != k) pthread_cond_wait(&L.cv, &L.mu);
-        pthread_mutex_unlock(&L.mu);
+        pthread_mutex_lock(&L->mu);
+        while (s->loaded != k) pthread_cond_wait(&L->cv, &L->mu);
+        pthread_mutex_unlock(&L->mu);
         t_wait_load += mono_s() - tw;
         if (s->io_error) { fprintf(stderr, "Error: %s: read failed\n", path); goto done; }
-        const size_t win0 = (size_t)k * L.W, win_end = win0 + L.W; /* blocks STARTING in [win0, win_end) are this chunk's */
+        const size_t win0 = (size_t)k * L->W, win_end = win0 + L->W; /* blocks STARTING in [win0, win_end) are this chunk's */
         int submitted_from_chunk = 0;
-        while (pos < win_end && pos < L.file_size) {
+        while (pos < win_end && pos < L->file_size) {
             if (pos < win0) { fprintf(stderr, "Error: %s: BGZF block chain lost\n", path); goto done; }
             uint64_t consumed = 0, inflated = 0;
             const double ts = mono_s();
@@ -335,7 +335,7 @@ int run_device_feed(pssbam_engine *const *eng, int n_gpus, const char *path, siz
             t_scan += mono_s() - ts;
             if (n < 0) { fprintf(stderr, "Error: %s: %s\n", path, pssbam_last_error()); goto done; }
             if (n == 0) {
-                if (win0 + s->len >= L.file_size) { fprintf(stderr, "Error: %s: truncated BGZF block at end of file\n", path); goto done; }
+                if (win0 + s->len >= L->file_size) { fprintf(stderr, "Error: %s: truncated BGZF block at end of file\n", path); goto done; }
                 fprintf(stderr, "Error: %s: BGZF block larger than the read-ahead\n", path);
                 goto done;
             }
@@ -382,23 +382,23 @@ int run_device_feed(pssbam_engine *const *eng, int n_gpus, const char *path, siz
                 const int q = (fifo_head + fifo_len) % 128;
                 fifo[q].chunk = k; fifo[q].g = g; fifo[q].ticket = ticket;
                 fifo_len++;
-                pending_of_chunk[k % L.n_st]++;
+                pending_of_chunk[k % L->n_st]++;
                 submitted_from_chunk++;
                 while (fifo_len > max_inflight || fifo_len >= 127) RETIRE();
                 i = j;
             }
         }
         if (!submitted_from_chunk) { /* nothing read this slot: give it straight back */
-            pthread_mutex_lock(&L.mu);
-            s->free_for = k + L.n_st;
+            pthread_mutex_lock(&L->mu);
+            s->free_for = k + L->n_st;
             s->loaded = -1;
-            pthread_cond_broadcast(&L.cv);
-            pthread_mutex_unlock(&L.mu);
+            pthread_cond_broadcast(&L->cv);
+            pthread_mutex_unlock(&L->mu);
         }
     }
     while (fifo_len > 0) RETIRE();
 #undef RETIRE
-    if (pos != L.file_size) { fprintf(stderr, "Error: %s: truncated BGZF block at end of file\n", path); goto done; }
+    if (pos != L->file_size) { fprintf(stderr, "Error: %s: truncated BGZF block at end of file\n", path); goto done; }
     fs->n_submits = n_submits;
     /* how the blocks fared: one word per engine */
     for (int g = 0; g < n_gpus; g++) {
@@ -420,22 +420,21 @@ int run_device_feed(pssbam_engine *const *eng, int n_gpus, const char *path, siz
         fprintf(stderr, "[pssbam] device feed: %llu submits, %.2f GB compressed over PCIe, %.2f GB inflated on the device in %.3f s "
                         "of kernel time (%.1f GB/s), %d loader threads, %d staging slots of %zu MiB%s\n",
                 (unsigned long long)n_submits, fs->compressed_bytes * 1e-9, fs->inflated_bytes * 1e-9, fs->inflate_ms * 1e-3,
-                fs->inflate_ms > 0 ? fs->inflated_bytes * 1e-6 / fs->inflate_ms : 0.0, n_th, L.n_st, L.W >> 20,
+                fs->inflate_ms > 0 ? fs->inflated_bytes * 1e-6 / fs->inflate_ms : 0.0, n_th, L->n_st, L->W >> 20,
                 fs->fallback ? "; records cross BGZF blocks -> host reader" : "");
     if (verbose)
         fprintf(stderr, "[pssbam] device feed, this thread: waiting for loaders %.3f, block-header walk %.3f (%ld of %ld windows walked by "
                         "their loader), submit (incl. waiting for a free super-batch) %.3f, waiting for copies %.3f s\n", t_wait_load, t_scan,
-                n_prescanned, L.n_chunks, t_submit, t_wait_copy);
+                n_prescanned, L->n_chunks, t_submit, t_wait_copy);
     rc = 0;
 done:
     if (rc) {   /* nothing may still read the staging slots */
-        pthread_mutex_lock(&L.mu);
-        L.stop = 1;
-        pthread_cond_broadcast(&L.cv);
-        pthread_mutex_unlock(&L.mu);
+        pthread_mutex_lock(&L->mu);
+        L->stop = 1;
+        pthread_cond_broadcast(&L->cv);
+        pthread_mutex_unlock(&L->mu);
         for (int g = 0; g < n_gpus; g++) (void)pssbam_engine_sync(eng[g]);
     }
-#undef L
     loader_close(F);
     free(blocks);
     free(grp);
