@@ -604,6 +604,90 @@ done:
     return rc;
 }
 
+/* Plain gzip: the stream is serial, but it need not be parsed a block at a time by the thread that inflates it --
+ * the whole text goes into memory through zlib (the file's ISIZE trailer sizes the buffer when the file has one
+ * member) and the multi-threaded parser takes it from there.  0 = not applicable (small, unreadable): gzread path. */
+static int load_gzip_whole(const char fn[], Genome **out)
+{
+    const int n_threads = fasta_threads();
+    if (n_threads < 2) return 0;
+    struct stat sb;
+    if (stat(fn, &sb) != 0 || !S_ISREG(sb.st_mode) || sb.st_size < 18) return 0;
+    uint32_t isize = 0;
+    {
+        FILE *f = fopen(fn, "rb");
+        if (!f) return 0;
+        if (fseeko(f, -4, SEEK_END) != 0 || fread(&isize, 1, 4, f) != 4) isize = 0;
+        fclose(f);
+    }
+    /* One member whose trailer says how much it inflates to (the usual `gzip ref.fa`): the block decoder of the BAM
+     * reader (host/inflate_fast.c) takes the whole DEFLATE stream in one call, several times zlib's speed; anything
+     * it does not like -- more members, > 4 GiB, a damaged stream -- goes through zlib below. */
+    if (isize >= (1u << 20)) {
+        int fd = open(fn, O_RDONLY);
+        const size_t size = (size_t)sb.st_size;
+        const unsigned char *data = fd >= 0 ? (const unsigned char *)mmap(NULL, size, PROT_READ, MAP_PRIVATE, fd, 0) : (const unsigned char *)MAP_FAILED;
+        if (fd >= 0) close(fd);
+        if (data != (const unsigned char *)MAP_FAILED) {
+            size_t o = 10;
+            int ok = size > 18 && data[0] == 0x1f && data[1] == 0x8b && data[2] == 8 && !(data[3] & 0xE0);
+            const unsigned flg = ok ? data[3] : 0;
+            if (ok && (flg & 4)) { ok = o + 2 <= size; if (ok) o += 2 + ((size_t)data[o] | ((size_t)data[o + 1] << 8)); }
+            for (int fld = 0; ok && fld < 2; fld++)   /* FNAME, FCOMMENT: zero-terminated */
+                if (flg & (fld ? 16u : 8u)) {
+                    while (o < size && data[o]) o++;
+                    o++;
+                }
+            if (ok && (flg & 2)) o += 2;
+            ok = ok && o + 8 < size;
+            unsigned char *text = ok ? (unsigned char *)contig_alloc((size_t)isize + 1) : NULL;
+            pss_inflater *st = text ? (pss_inflater *)malloc(sizeof *st) : NULL;
+            int rc = 0, done = 0;
+            if (st) {
+                uint32_t crc;
+                memcpy(&crc, data + size - 8, 4);
+                if (pss_inflate_raw(st, data + o, size - 8 - o, text, isize) == 0 && pss_crc32(0, text, isize) == crc) {
+                    rc = parse_parallel(text, isize, fn, n_threads, out);
+                    done = 1;
+                }
+            }
+            free(st);
+            free(text);
+            munmap((void *)data, size);
+            if (done) return rc;
+        }
+    }
+    gzFile zf = gzopen(fn, "rb");
+    if (!zf) return 0;
+    gzbuffer(zf, 1u << 20);
+    size_t cap = (size_t)isize + 1, len = 0;   /* (right for one member; FASTA text deflates 3.5-4.5x: room for several) */
+    if (cap < 5 * (size_t)sb.st_size) cap = 5 * (size_t)sb.st_size;
+    if (cap < ((size_t)64 << 20)) cap = (size_t)64 << 20;
+    unsigned char *text = (unsigned char *)contig_alloc(cap);
+    int rc = 0, bad = 0;
+    if (!text) { gzclose(zf); return 0; }
+    for (;;) {
+        if (len == cap) {
+            const size_t ncap = cap + cap / 2;
+            unsigned char *nt = (unsigned char *)contig_alloc(ncap);
+            if (!nt) { bad = 1; break; }
+            memcpy(nt, text, len);
+            free(text);
+            text = nt;
+            cap = ncap;
+        }
+        const size_t want = cap - len < ((size_t)256 << 20) ? cap - len : ((size_t)256 << 20);
+        const int got = gzread(zf, text + len, (unsigned)want);
+        if (got < 0) { bad = 1; break; }   /* damaged stream: the block-at-a-time path below deals with it as before */
+        if (got == 0) break;
+        len += (size_t)got;
+    }
+    gzclose(zf);
+    if (!bad && len >= ((size_t)1 << 20)) rc = parse_parallel(text, len, fn, n_threads, out);
+    free(text);
+    return rc;
+}
+
 Genome *init_genome(const char fn[])
 {
     Genome *genome;
@@ -619,6 +703,7 @@ Genome *init_genome(const char fn[])
     src.gz = is_gz(fn);
     if (!src.gz && load_parallel(fn, &genome)) return genome;
     if (src.gz && load_bgzf_parallel(fn, &genome)) return genome;
+    if (src.gz && load_gzip_whole(fn, &genome)) return genome;
     if (src.gz) {
         src.zf = gzopen(fn, "rb");
         if (!src.zf) {

@@ -159,7 +159,13 @@ def test_genome_loader_bgzf_fasta(host, tmp_path):
     bg.write_bytes(b"".join(tl.bgzf_block(raw[i:i + 0xFF00], 6) for i in range(0, len(raw), 0xFF00)) + tl.BGZF_EOF)
     gz = tmp_path / "ref.plain.fa.gz"
     gz.write_bytes(gzip.compress(raw, 1))
-    for path in (bg, gz):
+    gz2 = tmp_path / "ref.two_members.fa.gz"   # concatenated members, a header with a file name
+    gz2.write_bytes(gzip.compress(raw[:1_000_001], 6) + b"\x1f\x8b\x08\x08\0\0\0\0\0\x03part2.fa\0" + gzip.compress(raw[1_000_001:], 9)[10:])
+    gz3 = tmp_path / "ref.named.fa.gz"          # one member, FNAME set (what `gzip ref.fa` writes)
+    with open(gz3, "wb") as fh, gzip.GzipFile(filename="ref.fa", mode="wb", fileobj=fh, compresslevel=6, mtime=0) as z:
+        z.write(raw)
+    assert gz3.read_bytes()[3] & 8
+    for path in (bg, gz, gz2, gz3):
         for threads in ("16", "3", "1"):
             os.environ["PSSBAM_FASTA_THREADS"] = threads
             try:
