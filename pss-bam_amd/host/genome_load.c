@@ -426,9 +426,11 @@ static int parse_parallel(const unsigned char *data, size_t size, const char fn[
     if (!bad) fa_run(&job, 0, n_threads);
 
     /* size the contigs: segments in file order; a leading segment continues the open contig */
-    genome = (Genome *)malloc(sizeof(Genome));
+    genome = (Genome *)calloc(1, sizeof(Genome));
+    if (!genome) { applicable = 0; goto out; }
     genome->seqs = (Seq **)malloc(sizeof(Seq *) * MAX_GENOME_SEQS);
     genome->dummy = (Seq *)calloc(1, sizeof(Seq));
+    if (!genome->seqs || !genome->dummy) { applicable = 0; goto out; }
     genome->n_seqs = 0;
     for (int round = 0; round < 2 && !bad && applicable; round++) {
         /* round 0 adds up lengths, round 1 (after allocation) hands out destinations */
