@@ -962,8 +962,12 @@ __global__ void __launch_bounds__(256) bgzf_chain_verify(const uint8_t *out, con
             }
         }
         counts[b] = c;
-        if (b == 0u && nexta[0] == CHAIN_NONE) {   // not one record starts in this super-batch: all of it is tail
-            *tail_start = *first_start;
+        if (b == 0u) {
+            if (nexta[0] == CHAIN_NONE) *tail_start = *first_start;   // not one record starts in this super-batch: all of it is tail
+            // block 0 anchors the chain at *first_start; when it starts no record itself (an empty BGZF block at the
+            // head of the stream) the first candidate a LATER block found must be that very offset -- a candidate scan
+            // that skipped an implausible record there would drop it silently, where the host reader diagnoses it
+            else if (n[0] == 0u && nexta[0] != *first_start) atomicOr(flags, FEED_RAGGED);
         }
     }
 }

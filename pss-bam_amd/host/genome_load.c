@@ -32,11 +32,10 @@
 #include <errno.h>
 #include <fcntl.h>
 #include <pthread.h>
+#include <stdatomic.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
-
-#include <sys/mman.h>
 
 /* A contig's bases.  Big ones ask for transparent huge pages (the box runs THP in "madvise" mode):
  * a 3.1 Gb genome is 800 000 first-touch faults in 4 KiB pages and 1 500 in 2 MiB pages -- faster
@@ -503,25 +502,25 @@ typedef struct {
     const fa_bgzf_block *blk;
     size_t n_blk, next;
     pthread_mutex_t mu;
-    int bad;
+    atomic_int bad;   /* set by any worker, polled by all of them */
 } fa_bgzf_job;
 
 static void *fa_bgzf_worker(void *arg)
 {
     fa_bgzf_job *job = (fa_bgzf_job *)arg;
     pss_inflater *st = (pss_inflater *)malloc(sizeof *st);
-    if (!st) { job->bad = 1; return NULL; }
+    if (!st) { atomic_store(&job->bad, 1); return NULL; }
     for (;;) {
         pthread_mutex_lock(&job->mu);
         const size_t k0 = job->next;
         job->next += 64;
         pthread_mutex_unlock(&job->mu);
-        if (k0 >= job->n_blk || job->bad) break;
+        if (k0 >= job->n_blk || atomic_load(&job->bad)) break;
         for (size_t k = k0; k < k0 + 64 && k < job->n_blk; k++) {
             const fa_bgzf_block *b = &job->blk[k];
             if (!b->isize) continue;
             if (pss_inflate_raw(st, job->data + b->in_off, b->in_len, job->text + b->out_off, b->isize) != 0 ||
-                pss_crc32(0, job->text + b->out_off, b->isize) != b->crc) { job->bad = 1; break; }
+                pss_crc32(0, job->text + b->out_off, b->isize) != b->crc) { atomic_store(&job->bad, 1); break; }
         }
     }
     free(st);
@@ -591,7 +590,7 @@ static int load_bgzf_parallel(const char fn[], Genome **out)
         fa_bgzf_worker(&job);
         for (int t = 0; t < started; t++) pthread_join(th[t], NULL);
         pthread_mutex_destroy(&job.mu);
-        if (job.bad) {
+        if (atomic_load(&job.bad)) {
             fprintf(stderr, "%s: damaged BGZF block (inflate / CRC-32 check failed)\n", fn);
             *out = NULL;
             rc = 1;

@@ -321,7 +321,13 @@ def sam_line(r: Rec) -> str:
     f = [r.qname, str(r.flag), r.rname, str(r.pos), str(r.mapq), r.cigar_str(), r.rnext, str(r.pnext),
          str(r.tlen), r.seq, r.qual]
     for tag, typ, val in r.tags:
-        f.append(f"{tag}:{typ}:{val}")
+        if typ == "B":                      # (sub-type, values): TAG:B:<sub>,v,v,...
+            sub, vals = val
+            f.append(f"{tag}:B:{sub}" + "".join(f",{v:g}" if sub == "f" else f",{int(v)}" for v in vals))
+        elif typ == "f":
+            f.append(f"{tag}:f:{float(val):g}")
+        else:
+            f.append(f"{tag}:{typ}:{val}")
     return "\t".join(f) + "\n"
 
 
@@ -381,10 +387,20 @@ def bam_record(r: Rec, ref_index: dict[str, int]) -> bytes:
                 aux += t + b"c" + struct.pack("<b", v)
             elif 0 <= v < 65536:
                 aux += t + b"S" + struct.pack("<H", v)
+            elif -32768 <= v < 0:
+                aux += t + b"s" + struct.pack("<h", v)
+            elif v >= 1 << 31:
+                aux += t + b"I" + struct.pack("<I", v)
             else:
                 aux += t + b"i" + struct.pack("<i", v)
         elif typ == "f":
             aux += t + b"f" + struct.pack("<f", float(val))
+        elif typ == "H":
+            aux += t + b"H" + str(val).encode() + b"\0"
+        elif typ == "B":
+            sub, vals = val
+            fmt = {"c": "b", "C": "B", "s": "h", "S": "H", "i": "i", "I": "I", "f": "f"}[sub]
+            aux += t + b"B" + sub.encode() + struct.pack("<I", len(vals)) + struct.pack(f"<{len(vals)}{fmt}", *vals)
         else:
             raise ValueError(typ)
     pos0 = r.pos - 1
@@ -506,10 +522,48 @@ def random_contig(rng: np.random.Generator, n: int, lower_frac: float = 0.3, n_f
 _COMP = str.maketrans("ACGTacgt", "TGCAtgca")
 
 
-def fuzz_dataset(seed: int, n_reads: int = 1500, contig_lens=(5000, 1200, 300), with_rg: bool = False):
+_B_RANGE = {"c": (-128, 128), "C": (0, 256), "s": (-32768, 32768), "S": (0, 65536), "i": (-(1 << 31), 1 << 31),
+            "I": (0, 1 << 32)}
+
+
+def random_aux(rng: np.random.Generator, max_count: int = 24) -> tuple:
+    """one optional field of a type the -R walk has to step over (SAM spec 4.2.4): B arrays of every
+    sub-type (count 0 included), H, f, the small / negative / large integer encodings, and values whose
+    bytes spell an RG:Z field themselves"""
+    u = int(rng.integers(0, 10))
+    if u < 3:
+        sub = "cCsSiIf"[int(rng.integers(0, 7))]
+        n = 0 if rng.random() < 0.2 else int(rng.integers(1, max_count + 1))
+        if sub == "f":
+            vals = [float(np.float32(x)) for x in rng.normal(0, 50, size=n)]
+        else:
+            lo, hi = _B_RANGE[sub]
+            vals = [int(x) for x in rng.integers(lo, hi, size=n)]
+        return ("ML" if sub == "C" else "Z" + sub, "B", (sub, vals))
+    if u == 3:
+        return ("XH", "H", "".join("0123456789ABCDEF"[int(x)] for x in rng.integers(0, 16, size=2 * int(rng.integers(0, 12)))))
+    if u == 4:
+        return ("XF", "f", float(np.float32(rng.normal(0, 1000))))
+    if u == 5:
+        return ("XS", "i", int(rng.integers(-32768, -128)))            # 's' in BAM
+    if u == 6:
+        return ("XI", "i", int(rng.integers(1 << 31, 1 << 32)))         # 'I' in BAM
+    if u == 7:
+        return ("XW", "i", int(rng.integers(-(1 << 31), -32768)))       # 'i' in BAM
+    if u == 8:
+        return ("XZ", "Z", "RGZgrp" + "AB"[int(rng.integers(0, 2))])    # a value that LOOKS like the field
+    return ("XB", "B", ("C", [82, 71, 90, 103, 114, 112, 65 + int(rng.integers(0, 2)), 0]))   # "RGZgrpA\0" as array bytes
+
+
+def fuzz_dataset(seed: int, n_reads: int = 1500, contig_lens=(5000, 1200, 300), with_rg: bool = False,
+                 extras: bool | None = None):
     """A genome + alignments that poke at every branch of both process_aln functions.
-    Returns (contigs[(id, text)], refs[(name, len)] for the BAM header, recs)."""
+    Returns (contigs[(id, text)], refs[(name, len)] for the BAM header, recs).
+    extras (default: with_rg): aux fields of every type around RG:Z, MAPQ 255, read names of 200+
+    characters."""
     rng = np.random.default_rng(seed)
+    if extras is None:
+        extras = with_rg
     names = ["chrB", "chrA", "scaffold_10", "tiny.4", "tiny.5", "tiny.6"][:len(contig_lens)]
     contigs = [(nm, random_contig(rng, ln)) for nm, ln in zip(names, contig_lens)]
     refs = [(nm, len(s)) for nm, s in contigs] + [("chrMissing", 4000)]   # in BAM header, not in FASTA
@@ -604,8 +658,17 @@ def fuzz_dataset(seed: int, n_reads: int = 1500, contig_lens=(5000, 1200, 300), 
                 tags.insert(0 if rng.random() < 0.5 else len(tags), ("NM", "i", int(rng.integers(0, 400))))
             if rng.random() < 0.2:
                 tags.insert(0, ("XA", "A", "q"))
-        recs.append(Rec(qname=f"r{i:07d}", flag=flag, rname=rname, pos=s + 1 if rng.random() > 0.005 else 0,
-                        mapq=int(rng.integers(0, 61)), cigar=cigar, tlen=tlen, seq=seq, qual=qual, tags=tags))
+        pos1 = s + 1 if rng.random() > 0.005 else 0
+        qname, mapq = f"r{i:07d}", int(rng.integers(0, 61))
+        if extras:
+            for _ in range(int(rng.integers(0, 4))):                  # in front of / behind / between the fields so far
+                tags.insert(int(rng.integers(0, len(tags) + 1)), random_aux(rng))
+            if rng.random() < 0.05:
+                mapq = 255                                            # "mapping quality not available"
+            if rng.random() < 0.04:
+                qname += "_" + "x" * int(rng.integers(192, 246))      # l_read_name up to 254 + NUL
+        recs.append(Rec(qname=qname, flag=flag, rname=rname, pos=pos1,
+                        mapq=mapq, cigar=cigar, tlen=tlen, seq=seq, qual=qual, tags=tags))
     return contigs, refs, recs
 
 
@@ -629,7 +692,7 @@ def random_pss_opts(rng: np.random.Generator) -> PssOpts:
     ctx_choices = ["ACGT", "ACGT", "ACGT", "CT", "G", "ACGTN", "TA", "N", "NR", "ACGTNRY", "acgt", "GY"]
     lo = int(rng.choice([0, 0, 10, 25]))
     hi = int(rng.choice([250000000, 250000000, 60, 120]))
-    return PssOpts(region_len=int(rng.choice([1, 5, 8, 15, 25, 30, 31, 40, 70])), min_read_len=lo,
+    return PssOpts(region_len=int(rng.choice([1, 5, 8, 15, 16, 17, 25, 30, 31, 40, 70])), min_read_len=lo,
                    max_read_len=hi, min_mq=int(rng.choice([0, 0, 20, 37])),
                    up_ctx=str(rng.choice(ctx_choices)), down_ctx=str(rng.choice(ctx_choices)),
                    merged_only=bool(rng.random() < 0.3))

@@ -56,6 +56,18 @@ def stress_files(tmp_path_factory):
     (d / "a.sam.gz").write_bytes(gzip.compress((d / "a.sam").read_bytes()))
     tl.write_bam(d / "ragged.bam", refs, recs, level=1, rng=np.random.default_rng(5), block=6000)
     tl.write_bam(d / "whole.bam", refs, recs, level=6)
+    # FASTA files above the parallel .gz loaders' 1 MiB threshold (host/genome_load.c: fa_bgzf_worker /
+    # load_bgzf_parallel / load_gzip_whole), in the three shapes they tell apart: bgzip blocks, one gzip
+    # member, two gzip members
+    rng = np.random.default_rng(99)
+    big = [(f"big{k}", tl.random_contig(rng, n)) for k, n in enumerate((1_300_000, 700_000, 40_000, 300_000))]
+    tl.write_fasta(d / "big.fa", big)
+    text = (d / "big.fa").read_bytes()
+    assert len(text) > 2 << 20
+    (d / "big.bgzf.fa.gz").write_bytes(b"".join(tl.bgzf_block(text[i:i + 0xFF00], 6) for i in range(0, len(text), 0xFF00)) + tl.BGZF_EOF)
+    (d / "big.one.fa.gz").write_bytes(gzip.compress(text, 6))
+    cut = text.index(b"\n", len(text) // 2) + 1
+    (d / "big.two.fa.gz").write_bytes(gzip.compress(text[:cut], 6) + gzip.compress(text[cut:], 1))
     return d
 
 
@@ -67,6 +79,12 @@ def test_host_readers_under_sanitizers(san, stress_files, flavour):
     cases = [["-f", GOLD / "setA.fa", "-a", GOLD / "setA.bam"], ["-f", GOLD / "setB.fa", "-a", GOLD / "setB.sam"],
              ["-f", d / "g.fa", "-a", d / "ragged.bam"], ["-f", d / "g.fa.gz", "-a", d / "whole.bam"],
              ["-a", d / "a.sam"], ["-a", d / "a.sam.gz"]]
+    # the threaded .gz FASTA loaders: same genome digest as the plain file, eight parser / inflate threads
+    want_big = _run(plain_hc, ["-f", d / "big.fa"])
+    for gz in ("big.bgzf.fa.gz", "big.one.fa.gz", "big.two.fa.gz"):
+        assert _run(plain_hc, ["-f", d / gz]) == want_big, gz
+        assert _run(hc, ["-f", d / gz], {"PSSBAM_FASTA_THREADS": "8"}) == want_big, gz
+    assert _run(hc, ["-f", d / "big.fa"], {"PSSBAM_FASTA_THREADS": "8"}) == want_big
     for args in cases:
         want = _run(plain_hc, args)
         assert _run(hc, args) == want, args
