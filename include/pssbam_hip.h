@@ -42,6 +42,7 @@ extern "C" {
 #define PSSBAM_ENOMEM (-4)
 #define PSSBAM_ESTATE (-5)   /* call order violated (e.g. submit before set_genome)      */
 #define PSSBAM_EFORMAT (-6)  /* malformed record block                                   */
+#define PSSBAM_EBUSY (-7)    /* pssbam_engine_submit_bgzf before the genome: every feed slot is full; set the genome first */
 
 /* which tallies one pass produces */
 #define PSSBAM_TALLY_PSS 1u   /* substitution tables, pss-bam.c process_aln              */
@@ -122,6 +123,13 @@ int pssbam_engine_set_stream(pssbam_engine *e, void *hip_stream);
  * find_seq's strcmp semantics (fasta-genome-io.c:202-219).  The Genome stays owned by
  * the caller and may be destroyed afterwards. */
 int pssbam_engine_set_genome(pssbam_engine *e, const struct genome *g);
+/* The same without the wait: returns once the upload is enqueued (copies, case folding and 4-bit packing
+ * run on a stream of their own; tally launches wait for them on the device), so one host thread can start
+ * the uploads of several GPUs at once and the engine's stream keeps inflating meanwhile.  The Genome must
+ * stay untouched until pssbam_engine_genome_wait, _sync or _finish has returned.  The reference loads the
+ * genome, then loops (pss-bam.c:751-783); this is what lets the replacement overlap the two. */
+int pssbam_engine_set_genome_async(pssbam_engine *e, const struct genome *g);
+int pssbam_engine_genome_wait(pssbam_engine *e);
 
 /* Same from plain arrays; when seqs_on_device != 0 the seqs[i] are device pointers
  * (bench / generators) and are copied device-to-device. */
@@ -246,6 +254,15 @@ int pssbam_bgzf_inflate_device(void *hip_stream, const void *d_comp, uint64_t co
 int pssbam_engine_submit_bgzf(pssbam_engine *e, const void *comp, uint64_t comp_bytes, const pssbam_bgzf_block *blocks,
                               uint32_t n_blocks, uint32_t first_record_offset, uint64_t *ticket);
 int pssbam_engine_wait_bgzf_copied(pssbam_engine *e, uint64_t ticket);
+/* Optional, BEFORE set_genome: declares that compressed blocks will be fed ahead of the genome.  n_ref = the
+ * reference count of the BAM header (the record chain is judged with it; set_references must bring the same
+ * count later).  pssbam_engine_submit_bgzf is then legal at once: inflate, CRC-32 and record index run as the
+ * blocks arrive -- they need no reference base -- and the tally launches of every super-batch follow when
+ * set_genome(_async) + set_references have been called.  The inflated records wait in device memory meanwhile
+ * (a ring of 4.4 GB slots that grows within what the device has free, genome_bytes_hint -- e.g. the FASTA's
+ * size, 0 = unknown -- left alone); when every slot is full submit_bgzf returns PSSBAM_EBUSY and has taken
+ * NOTHING of that chunk: set the genome, then submit the chunk again. */
+int pssbam_engine_feed_open(pssbam_engine *e, int32_t n_ref, uint64_t genome_bytes_hint);
 /* The blocks submitted next do NOT continue the stream fed so far (an engine that is dealt every n-th
  * run of a file): pending blocks are processed, a partial record left at this point raises
  * PSSBAM_FEED_TRUNCATED, and the next blocks start a new record chain at their first byte. */
@@ -260,9 +277,11 @@ int pssbam_engine_feed_status(pssbam_engine *e, uint32_t *flags, double *inflate
  * memory (e.g. the first ones of the file) from which the tiled kernels' staged record prefix is
  * sized -- otherwise the engine reads the first block back from the device to look at its records. */
 int pssbam_engine_hint_records(pssbam_engine *e, const void *records, uint64_t nbytes);
-/* Optional: allocates the feed's device buffers (~17 GB) for `device` ahead of time, e.g. from a helper
- * thread while the FASTA loads; the first engine on that device that feeds compressed blocks takes them. */
+/* Optional: allocates two of the feed's slots (2 x (2 GiB compressed + 4.5 GiB inflated) = ~13 GB) for
+ * `device` ahead of time, e.g. from a helper thread while the FASTA loads; the first engine on that device
+ * that feeds compressed blocks takes them.  pssbam_feed_release frees what no engine took. */
 int pssbam_feed_reserve(int device);
+int pssbam_feed_release(int device);
 
 /* Test / tool convenience: host BGZF bytes in, inflated bytes out (out may be NULL), kernels timed
  * with HIP events (*kernel_ms = best of `repeats` runs of inflate + CRC). */

@@ -39,7 +39,9 @@ HIP_SYMBOLS = [
     "pssbam_engine_timer_end", "pssbam_engine_kernel_time", "pssbam_index_records", "pssbam_bgzf_scan",
     "pssbam_bgzf_inflate_device", "pssbam_bgzf_inflate_host", "pssbam_engine_submit_bgzf", "pssbam_engine_wait_bgzf_copied",
     "pssbam_engine_feed_status", "pssbam_engine_feed_break", "pssbam_feed_reserve", "pssbam_engine_hint_records",
+    "pssbam_engine_set_genome_async", "pssbam_engine_genome_wait", "pssbam_engine_feed_open", "pssbam_feed_release",
 ]
+EBUSY = -7
 
 
 def build(verbose: bool = False) -> None:
@@ -263,10 +265,17 @@ class Engine:
         _chk(self._L.pssbam_engine_phase_times(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
         return {"h2d_ms": a.value, "h2d_bytes": b.value, "kernel_ms": c.value, "launches": d.value}
 
-    def submit_bgzf(self, bgzf: np.ndarray, header_bytes: int = 0, max_batch_inflated: int = 1 << 30) -> int:
+    def feed_open(self, n_ref: int, genome_bytes_hint: int = 0):
+        """compressed blocks may be fed before set_genome / set_references; their tallies follow then"""
+        self._L.pssbam_engine_feed_open.argtypes = [C.c_void_p, C.c_int32, C.c_uint64]
+        _chk(self._L.pssbam_engine_feed_open(self._h, n_ref, genome_bytes_hint))
+
+    def submit_bgzf(self, bgzf: np.ndarray, header_bytes: int = 0, max_batch_inflated: int = 1 << 30, on_busy=None) -> int:
         """Whole BGZF blocks (host bytes) through the device-side feed: inflate, CRC, record index and
         tally on the GPU.  header_bytes = inflated bytes in front of the first alignment record (the BAM
-        header when `bgzf` starts at the beginning of the file).  Returns the number of blocks."""
+        header when `bgzf` starts at the beginning of the file).  Returns the number of blocks.
+        on_busy: called when the engine answers PSSBAM_EBUSY (fed ahead of the genome, every slot full); it
+        must set the genome and references, after which the chunk is submitted again."""
         class _Blk(C.Structure):
             _fields_ = [("in_off", C.c_uint64), ("in_len", C.c_uint32), ("isize", C.c_uint32), ("out_off", C.c_uint64),
                         ("crc", C.c_uint32), ("status", C.c_uint32)]
@@ -301,7 +310,11 @@ class Engine:
                 grp[k - i].out_off -= base_out
             end_in = blocks[j - 1].in_off + blocks[j - 1].in_len
             t = C.c_uint64()
-            _chk(L.pssbam_engine_submit_bgzf(self._h, bgzf.ctypes.data + base_in, end_in - base_in, grp, j - i, skip, C.byref(t)))
+            rc = L.pssbam_engine_submit_bgzf(self._h, bgzf.ctypes.data + base_in, end_in - base_in, grp, j - i, skip, C.byref(t))
+            if rc == EBUSY and on_busy is not None:
+                on_busy()
+                rc = L.pssbam_engine_submit_bgzf(self._h, bgzf.ctypes.data + base_in, end_in - base_in, grp, j - i, skip, C.byref(t))
+            _chk(rc)
             _chk(L.pssbam_engine_wait_bgzf_copied(self._h, t.value))
             skip = 0
             i = j

@@ -201,13 +201,15 @@ extern "C" int pssbam_bgzf_inflate_host(int device, const void *bgzf, uint64_t n
 // --------------------------------------------------------------------------------------
 // the feed: compressed chunks -> device inflate -> device record index -> tally
 // --------------------------------------------------------------------------------------
-// The inflate kernel runs one lane per BGZF block, so it wants hundreds of thousands of blocks per
-// launch (49 152 lanes are resident; a 1 GiB batch holds 16 000 blocks).  submit_bgzf therefore only
-// COPIES its chunk and appends its blocks to the super-batch being assembled; when that has
-// collected feed_out_target bytes of output (12 GiB: ~200 000 blocks, four rounds of lanes) it is
-// flushed: one inflate launch + one CRC launch over all blocks, then per < 4 GiB sub-batch (the
-// tally kernels index records with u32 offsets) the record index and the tally.  Two super-batches
-// alternate, so chunks keep arriving over PCIe while the previous one is inflated.
+// The inflate kernel runs one lane per BGZF block, 65 536 lanes resident: it wants whole "rounds" of that many
+// blocks per launch (a 1 GiB batch holds 16 000 blocks).  submit_bgzf therefore only COPIES its chunk and
+// appends its blocks to the super-batch being assembled; when that holds one round (4.3 GB of output) it is
+// flushed: one inflate launch + one CRC launch over all blocks, then per < 4 GiB sub-batch (the tally kernels
+// index records with u32 offsets) the record index and the tally.  Super-batches live in a ring of slots, so
+// chunks keep arriving over PCIe while earlier ones are inflated -- and, after pssbam_engine_feed_open, while
+// the GENOME is still on its way: inflate, CRC and record index need no reference base, so they run at once and
+// only the tally launches of a super-batch are put off until set_genome + set_references have been called (the
+// ring grows meanwhile, within what the device has free).
 static double feed_now() {
     timespec ts;
     clock_gettime(CLOCK_MONOTONIC, &ts);
@@ -227,8 +229,9 @@ static int grow(T **ptr, size_t *cap, size_t need, size_t elem = sizeof(T)) {
 static constexpr uint64_t FEED_SUB_MAX = (3584ull << 20);   // records per tally launch: below 4 GiB
 
 // Device buffers of the feed can be reserved ahead of the first submit (pssbam_feed_reserve, from a
-// helper thread while the caller still loads its FASTA): allocating ~17 GB takes from a millisecond
-// to a second depending on what the driver has to reclaim.
+// helper thread while the caller still loads its FASTA): allocating ~13 GB takes from a millisecond
+// to a second depending on what the driver has to reclaim.  What no engine took goes back with
+// pssbam_feed_release.
 namespace {
 struct FeedReserve { uint8_t *comp[2] = {nullptr, nullptr}, *out[2] = {nullptr, nullptr}; size_t comp_cap = 0, out_cap = 0; };
 FeedReserve g_feed_reserve[64];
@@ -240,13 +243,13 @@ extern "C" int pssbam_feed_reserve(int device) {
     HIP_TRY(hipSetDevice(device));
     FeedReserve r;
     r.comp_cap = (size_t)FEED_COMP_CAP;
-    r.out_cap = (size_t)(FEED_OUT_TARGET + FEED_OUT_SLACK);
+    r.out_cap = (size_t)(FEED_GAP + FEED_OUT_TARGET + FEED_OUT_SLACK);
     for (int k = 0; k < 2; k++) {
         HIP_TRY(hipMalloc(&r.comp[k], r.comp_cap + 64));
         HIP_TRY(hipMalloc(&r.out[k], r.out_cap));
     }
     std::lock_guard<std::mutex> lk(g_feed_reserve_mu);
-    if (g_feed_reserve[device].comp[0]) {   // somebody was faster: keep theirs
+    if (g_feed_reserve[device].comp[0] || g_feed_reserve[device].comp[1]) {   // somebody was faster: keep theirs
         for (int k = 0; k < 2; k++) { (void)hipFree(r.comp[k]); (void)hipFree(r.out[k]); }
         return PSSBAM_OK;
     }
@@ -254,12 +257,29 @@ extern "C" int pssbam_feed_reserve(int device) {
     return PSSBAM_OK;
 }
 
+extern "C" int pssbam_feed_release(int device) {
+    if (device < 0 || device >= 64) return fail(PSSBAM_EINVAL, "device %d out of range", device);
+    FeedReserve r;
+    {
+        std::lock_guard<std::mutex> lk(g_feed_reserve_mu);
+        r = g_feed_reserve[device];
+        g_feed_reserve[device] = FeedReserve();
+    }
+    if (!r.comp[0] && !r.comp[1]) return PSSBAM_OK;
+    HIP_TRY(hipSetDevice(device));
+    for (int k = 0; k < 2; k++) {
+        if (r.comp[k]) (void)hipFree(r.comp[k]);
+        if (r.out[k]) (void)hipFree(r.out[k]);
+    }
+    return PSSBAM_OK;
+}
+
 // takes one (comp, out) pair from the device's reserve, if there is one of the wanted size
-static bool feed_take_reserved(int device, size_t comp_cap, uint8_t **comp, uint8_t **out, size_t *out_cap) {
+static bool feed_take_reserved(int device, size_t comp_cap, size_t out_need, uint8_t **comp, uint8_t **out, size_t *out_cap) {
     if (device < 0 || device >= 64) return false;
     std::lock_guard<std::mutex> lk(g_feed_reserve_mu);
     FeedReserve &r = g_feed_reserve[device];
-    if (r.comp_cap != comp_cap) return false;
+    if (r.comp_cap != comp_cap || r.out_cap < out_need) return false;
     for (int k = 0; k < 2; k++)
         if (r.comp[k]) {
             *comp = r.comp[k];
@@ -271,25 +291,114 @@ static bool feed_take_reserved(int device, size_t comp_cap, uint8_t **comp, uint
     return false;
 }
 
+static bool feed_engine_ready(const pssbam_engine *e) { return e->d_genome && e->have_refs; }
+
+// what one slot of the ring costs in device memory (buffers + offset index), for the budget
+static uint64_t feed_slot_bytes(const pssbam_engine *e) {
+    const uint64_t out = FEED_GAP + e->feed_out_target + FEED_OUT_SLACK;
+    return out + e->feed_comp_cap + out / 8 + (64ull << 20);
+}
+
 // buffers of a super-batch that do not depend on its contents
 static int feed_prepare(pssbam_engine *e, FeedAcc &s) {
+    const size_t out_need = (size_t)(FEED_GAP + e->feed_out_target + FEED_OUT_SLACK);
     if (!s.d_comp) {
         s.comp_cap = (size_t)e->feed_comp_cap;
-        if (!feed_take_reserved(e->device, s.comp_cap, &s.d_comp, &s.d_out, &s.out_cap)) HIP_TRY(hipMalloc(&s.d_comp, s.comp_cap + 64));
+        if (!feed_take_reserved(e->device, s.comp_cap, out_need, &s.d_comp, &s.d_out, &s.out_cap)) HIP_TRY(hipMalloc(&s.d_comp, s.comp_cap + 64));
     }
     if (!s.d_out) {
-        int rc = grow(&s.d_out, &s.out_cap, (size_t)(e->feed_out_target + FEED_OUT_SLACK));
+        int rc = grow(&s.d_out, &s.out_cap, out_need);
         if (rc) return rc;
     }
     if (!s.d_chain) {
         HIP_TRY(hipMalloc(&s.d_chain, 2 * sizeof(uint64_t)));
         HIP_TRY(hipMemsetAsync(s.d_chain, 0, 2 * sizeof(uint64_t), e->stream));
     }
+    if (!s.consumed) HIP_TRY(hipEventCreateWithFlags(&s.consumed, hipEventDisableTiming));
+    return PSSBAM_OK;
+}
+
+// A slot to assemble the next super-batch in.  Order of preference: one that is free, one whose kernels have
+// completed, a new one (three while the engine is ready, as many as the memory budget allows while tallies are put
+// off), the oldest one still running (wait for it).  PSSBAM_EBUSY: every slot is full of inflated records that wait
+// for the genome -- unless `force`, which then goes past the budget.
+static int feed_acquire(pssbam_engine *e, int *out_slot, bool force) {
+    int oldest = -1;
+    for (size_t i = 0; i < e->feed.size(); i++) {
+        FeedAcc &s = *e->feed[i];
+        if ((int)i == e->cur_feed || (int)i == e->spare_feed) continue;
+        if (!s.busy) { *out_slot = (int)i; return PSSBAM_OK; }
+        if (!s.held && (oldest < 0 || s.flush_seq < e->feed[(size_t)oldest]->flush_seq)) oldest = (int)i;
+    }
+    if (oldest >= 0 && hipEventQuery(e->feed[(size_t)oldest]->consumed) == hipSuccess) {
+        e->feed[(size_t)oldest]->busy = false;
+        *out_slot = oldest;
+        return PSSBAM_OK;
+    }
+    (void)hipGetLastError();   // (hipErrorNotReady is not an error)
+    size_t limit = FEED_SLOTS_READY;
+    if (!feed_engine_ready(e)) {
+        if (!e->feed_mem_budget) {
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 64ull << 30;
+            const uint64_t used = e->feed.size() * feed_slot_bytes(e);
+            e->feed_mem_budget = used + (free_b > (24ull << 30) ? free_b - (24ull << 30) : 0);   // leaves room for genome, 4-bit image, k-mer bins
+        }
+        limit = std::max<size_t>(FEED_SLOTS_READY, (size_t)(e->feed_mem_budget / feed_slot_bytes(e)));
+        if (const char *v = getenv("PSSBAM_FEED_MAX_SLOTS")) limit = std::max<size_t>(1, (size_t)atoi(v));
+    }
+    limit = std::min<size_t>(limit, FEED_SLOTS_MAX);
+    if (e->feed.size() < limit || (force && oldest < 0 && e->feed.size() < (size_t)FEED_SLOTS_MAX)) {
+        const double t0 = feed_now();
+        FeedAcc *s = new FeedAcc();
+        e->feed.push_back(s);
+        const int rc = feed_prepare(e, *s);
+        e->feed_t_alloc += feed_now() - t0;
+        if (rc) return rc;
+        e->feed_slots_allocated++;
+        *out_slot = (int)e->feed.size() - 1;
+        return PSSBAM_OK;
+    }
+    if (oldest >= 0) {
+        const double t0 = feed_now();
+        HIP_TRY(hipEventSynchronize(e->feed[(size_t)oldest]->consumed));
+        e->feed_t_wait_busy += feed_now() - t0;
+        e->feed[(size_t)oldest]->busy = false;
+        *out_slot = oldest;
+        return PSSBAM_OK;
+    }
+    return fail(PSSBAM_EBUSY, "all %zu feed slots hold inflated records that wait for set_genome / set_references", e->feed.size());
+}
+
+// the tally launches of one flushed super-batch; `consumed` is recorded behind the last of them
+static int feed_launch_tally(pssbam_engine *e, const DeferredTally &d) {
+    FeedAcc &s = *e->feed[(size_t)d.slot];
+    int rc = launch_tally(e, s.d_out + d.sub_base, d.sub_len, s.d_offs + d.offs_at, d.n_bound, nullptr, 0, s.d_nrecs + d.k, d.sample_off);
+    if (rc) return rc;
+    if (d.last_of_slot) {
+        HIP_TRY(hipEventRecord(s.consumed, e->stream));
+        s.held = false;
+    }
+    return PSSBAM_OK;
+}
+
+// set_genome + set_references have both been called: the super-batches inflated ahead of them are tallied
+static int feed_resume(pssbam_engine *e) {
+    if (e->deferred.empty() || !feed_engine_ready(e)) return PSSBAM_OK;
+    HIP_TRY(hipSetDevice(e->device));
+    std::vector<DeferredTally> todo;
+    todo.swap(e->deferred);
+    for (const DeferredTally &d : todo) {
+        const int rc = feed_launch_tally(e, d);
+        if (rc) return rc;
+        e->feed_deferred_launches++;
+    }
     return PSSBAM_OK;
 }
 
 static int feed_flush(pssbam_engine *e) {
-    FeedAcc &s = e->feed[e->cur_feed];
+    if (e->cur_feed < 0) return PSSBAM_OK;
+    FeedAcc &s = *e->feed[(size_t)e->cur_feed];
     if (s.blocks.empty()) return PSSBAM_OK;
     int rc;
     const double t_flush0 = feed_now();
@@ -297,22 +406,23 @@ static int feed_flush(pssbam_engine *e) {
     const size_t nb = s.blocks.size();
     if (nb > 0xFFFFFFF0ull) return fail(PSSBAM_EINVAL, "too many BGZF blocks in one super-batch");
     if (s.blocks_cap < nb) {
+        const size_t want = std::max<size_t>(nb, e->feed_block_target < 0xFFFFFFFFull ? (size_t)e->feed_block_target : 0);
         size_t c[8] = {s.blocks_cap, s.blocks_cap, s.blocks_cap, s.blocks_cap, s.blocks_cap, s.blocks_cap, s.blocks_cap, s.blocks_cap};
-        if ((rc = grow((uint8_t **)&s.d_blocks, &c[0], nb, sizeof(pssbam::BgzfBlock)))) return rc;
-        if ((rc = grow(&s.d_a, &c[1], nb))) return rc;
-        if ((rc = grow(&s.d_e, &c[2], nb))) return rc;
-        if ((rc = grow(&s.d_last, &c[3], nb))) return rc;
-        if ((rc = grow(&s.d_nexta, &c[4], nb + 1))) return rc;
-        if ((rc = grow(&s.d_n, &c[5], nb))) return rc;
-        if ((rc = grow(&s.d_counts, &c[6], nb))) return rc;
-        if ((rc = grow(&s.d_base, &c[7], nb))) return rc;
+        if ((rc = grow((uint8_t **)&s.d_blocks, &c[0], want, sizeof(pssbam::BgzfBlock)))) return rc;
+        if ((rc = grow(&s.d_a, &c[1], want))) return rc;
+        if ((rc = grow(&s.d_e, &c[2], want))) return rc;
+        if ((rc = grow(&s.d_last, &c[3], want))) return rc;
+        if ((rc = grow(&s.d_nexta, &c[4], want + 1))) return rc;
+        if ((rc = grow(&s.d_n, &c[5], want))) return rc;
+        if ((rc = grow(&s.d_counts, &c[6], want))) return rc;
+        if ((rc = grow(&s.d_base, &c[7], want))) return rc;
         s.blocks_cap = *std::min_element(c, c + 8);
     }
     const uint64_t data_end = s.out_used;   // the blocks sit contiguously in [FEED_GAP, data_end)
     // (offsets: a block of isize bytes starts at most isize / 36 + 1 records, whatever its bytes are)
-    if ((rc = grow(&s.d_offs, &s.offs_cap, (size_t)(data_end / 36ull + nb + 2ull * s.sub_first.size() + 16ull)))) return rc;
-    if ((rc = grow(&s.d_nrecs, &s.nrecs_cap, s.sub_first.size()))) return rc;
-    if ((rc = feed_prepare(e, e->feed[e->cur_feed ^ 1]))) return rc;   // the tail goes into the other super-batch's gap
+    if ((rc = grow(&s.d_offs, &s.offs_cap, (size_t)(std::max<uint64_t>(data_end, FEED_GAP + e->feed_out_target) / 36ull + std::max<size_t>(nb, s.blocks_cap) + 2ull * s.sub_first.size() + 64ull)))) return rc;
+    if ((rc = grow(&s.d_nrecs, &s.nrecs_cap, std::max<size_t>(s.sub_first.size(), 4)))) return rc;
+    if (!e->d_carry) HIP_TRY(hipMalloc(&e->d_carry, FEED_GAP));
     // every chunk of this super-batch has been issued on the copy streams: the engine's stream waits for them
     if (!s.copies_done) {
         HIP_TRY(hipEventCreateWithFlags(&s.copies_done, hipEventDisableTiming));
@@ -342,6 +452,9 @@ static int feed_flush(pssbam_engine *e) {
         const uint64_t first = FEED_GAP + e->feed_skip;
         HIP_TRY(hipMemcpyAsync(s.d_chain, &first, sizeof first, hipMemcpyHostToDevice, e->stream));   // (pageable source: copied before the call returns)
         e->feed_fresh = false;
+    } else {               // the partial record the previous super-batch ended with goes in front of this one's data
+        hipLaunchKernelGGL(pssbam::bgzf_chain_carry_in, dim3(1), dim3(256), 0, e->stream, (const uint8_t *)e->d_carry, (const uint64_t *)e->d_feed_tail,
+                           s.d_out, (uint64_t)FEED_GAP, s.d_chain);
     }
     hipEvent_t ev0 = take_event(e), ev1 = take_event(e);
     if (!ev0 || !ev1) return fail(PSSBAM_EHIP, "hipEventCreate failed");
@@ -350,11 +463,12 @@ static int feed_flush(pssbam_engine *e) {
                         INFLATE_LOOP_DEFAULT, data_end - FEED_GAP);
     if (rc) return rc;
     // the record chain of the whole super-batch: per-block pieces, linked and checked
+    const int32_t n_ref = e->have_refs ? e->n_ref : e->feed_n_ref;
     {
         const uint32_t n = (uint32_t)nb, grid = std::min<uint32_t>((n + 255u) / 256u, (uint32_t)e->n_cu * 8u);
         const pssbam::BgzfBlock *blk = (const pssbam::BgzfBlock *)s.d_blocks;
         hipLaunchKernelGGL(pssbam::bgzf_chain_spec, dim3(grid), dim3(256), 0, e->stream, (const uint8_t *)s.d_out, blk, n, data_end,
-                           (const uint64_t *)s.d_chain, e->n_ref, s.d_a, s.d_n, s.d_e, s.d_last, e->d_feed_flags);
+                           (const uint64_t *)s.d_chain, n_ref, s.d_a, s.d_n, s.d_e, s.d_last, e->d_feed_flags);
         hipLaunchKernelGGL(pssbam::bgzf_chain_suffix, dim3(1), dim3(1024), 0, e->stream, (const uint64_t *)s.d_a, n, s.d_nexta);
         hipLaunchKernelGGL(pssbam::bgzf_chain_verify, dim3(grid), dim3(256), 0, e->stream, (const uint8_t *)s.d_out, (const uint32_t *)s.d_n, (const uint64_t *)s.d_e,
                            (const uint64_t *)s.d_last, (const uint64_t *)s.d_nexta, n, data_end, (const uint64_t *)s.d_chain, s.d_counts,
@@ -380,45 +494,41 @@ static int feed_flush(pssbam_engine *e) {
                            (const uint32_t *)(s.d_nrecs + k));
         offs_at += sub_len[k] / 36ull + n + 2ull;
     }
-    // the partial record at the end moves in front of the next super-batch's data
-    {
-        FeedAcc &o = e->feed[e->cur_feed ^ 1];
-        hipLaunchKernelGGL(pssbam::bgzf_chain_carry, dim3(1), dim3(256), 0, e->stream, (const uint8_t *)s.d_out, (const uint64_t *)(s.d_chain + 1), data_end,
-                           o.d_out, (uint64_t)FEED_GAP, o.d_chain, e->d_feed_tail, e->d_feed_flags);
-    }
+    // the partial record at the end sets out for the next super-batch (whichever slot that will be)
+    hipLaunchKernelGGL(pssbam::bgzf_chain_carry_out, dim3(1), dim3(256), 0, e->stream, (const uint8_t *)s.d_out, (const uint64_t *)(s.d_chain + 1), data_end,
+                       e->d_carry, (uint64_t)FEED_GAP, e->d_feed_tail, e->d_feed_flags);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev1, e->stream));
     e->inflate_events.emplace_back(ev0, ev1);
     e->inflated_bytes += data_end - FEED_GAP;
+    // the tally: now, or -- inflated ahead of the genome -- when set_references comes
+    const bool ready = feed_engine_ready(e);
     for (size_t k = 0; k < s.sub_first.size(); k++) {
-        rc = launch_tally(e, s.d_out + sub_base[k], sub_len[k], s.d_offs + sub_offs[k],
-                          (uint32_t)std::min<uint64_t>((k + 1 < sub_offs.size() ? sub_offs[k + 1] : offs_at) - sub_offs[k], 0xFFFFFFF0ull), nullptr, 0, s.d_nrecs + k,
-                          k == 0 ? FEED_GAP : 0ull);
-        if (rc) return rc;
+        DeferredTally d;
+        d.slot = e->cur_feed;
+        d.sub_base = sub_base[k];
+        d.sub_len = sub_len[k];
+        d.offs_at = sub_offs[k];
+        d.n_bound = (uint32_t)std::min<uint64_t>((k + 1 < sub_offs.size() ? sub_offs[k + 1] : offs_at) - sub_offs[k], 0xFFFFFFF0ull);
+        d.k = (uint32_t)k;
+        d.sample_off = k == 0 ? FEED_GAP : 0ull;
+        d.last_of_slot = k + 1 == s.sub_first.size();
+        s.held = true;
+        if (ready) { if ((rc = feed_launch_tally(e, d))) return rc; }
+        else e->deferred.push_back(d);
     }
-    if (!s.consumed) HIP_TRY(hipEventCreateWithFlags(&s.consumed, hipEventDisableTiming));
-    HIP_TRY(hipEventRecord(s.consumed, e->stream));
     s.busy = true;
+    s.flush_seq = ++e->flush_seq;
     s.blocks.clear();
     s.sub_first.clear();
     s.comp_used = s.out_used = s.sub_bytes = 0;
-    e->cur_feed ^= 1;
+    e->cur_feed = -1;
     return PSSBAM_OK;
 }
 
 // appends blocks[b0, b1) of a chunk (and their compressed bytes) to the super-batch being assembled
 static int feed_append(pssbam_engine *e, const uint8_t *comp, const pssbam_bgzf_block *blocks, uint32_t b0, uint32_t b1, hipStream_t cs) {
-    FeedAcc &s = e->feed[e->cur_feed];
-    int rc;
-    if (s.busy) {   // its previous super-batch must have been consumed before its buffers are overwritten
-        const double t0 = feed_now();
-        HIP_TRY(hipEventSynchronize(s.consumed));
-        e->feed_t_wait_busy += feed_now() - t0;
-        s.busy = false;
-    }
-    const double t_alloc0 = feed_now();
-    if ((rc = feed_prepare(e, s))) return rc;
-    e->feed_t_alloc += feed_now() - t_alloc0;
+    FeedAcc &s = *e->feed[(size_t)e->cur_feed];
     if (s.blocks.empty()) s.out_used = FEED_GAP;
     const uint64_t byte0 = blocks[b0].in_off & ~15ull, byte1 = blocks[b1 - 1].in_off + blocks[b1 - 1].in_len;
     const uint64_t out_bytes = blocks[b1 - 1].out_off + blocks[b1 - 1].isize - blocks[b0].out_off;
@@ -446,10 +556,32 @@ static int feed_append(pssbam_engine *e, const uint8_t *comp, const pssbam_bgzf_
     return PSSBAM_OK;
 }
 
+// Declares that compressed blocks will be fed BEFORE the genome is set: n_ref = the reference count of the BAM
+// header (the record chain is judged with it).  submit_bgzf is then legal at once; inflate, CRC-32 and the record
+// index run as the blocks arrive, the tally launches follow when set_genome(_async) + set_references have been
+// called.  genome_bytes_hint (0 = unknown): device memory to leave alone for the genome, e.g. the FASTA's size.
+extern "C" int pssbam_engine_feed_open(pssbam_engine *e, int32_t n_ref, uint64_t genome_bytes_hint) {
+    if (!e || n_ref < 0) return fail(PSSBAM_EINVAL, "bad argument");
+    if (e->cfg.kernel == PSSBAM_KERNEL_SIMPLE) return fail(PSSBAM_EINVAL, "device-indexed blocks need the tiled kernels");
+    HIP_TRY(hipSetDevice(e->device));
+    e->feed_opened = true;
+    e->feed_n_ref = n_ref;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+        const uint64_t keep = genome_bytes_hint + genome_bytes_hint / 2 + (8ull << 30);   // genome + 4-bit image + slack
+        e->feed_mem_budget = e->feed.size() * feed_slot_bytes(e) + (free_b > keep ? free_b - keep : 0);
+    }
+    return PSSBAM_OK;
+}
+
 extern "C" int pssbam_engine_submit_bgzf(pssbam_engine *e, const void *comp, uint64_t comp_bytes, const pssbam_bgzf_block *blocks,
                                          uint32_t n_blocks, uint32_t first_record_offset, uint64_t *ticket) {
-    int rc = check_ready(e);
-    if (rc) return rc;
+    if (!e) return fail(PSSBAM_EINVAL, "null engine");
+    if (!feed_engine_ready(e) && !e->feed_opened) {
+        int rc = check_ready(e);
+        if (rc) return rc;
+    }
+    int rc;
     if (ticket) *ticket = 0;
     if (!n_blocks) return PSSBAM_OK;
     if (!comp || !blocks) return fail(PSSBAM_EINVAL, "null buffer");
@@ -466,7 +598,8 @@ extern "C" int pssbam_engine_submit_bgzf(pssbam_engine *e, const void *comp, uin
         if (i && (b.in_off < blocks[i - 1].in_off + blocks[i - 1].in_len || b.out_off != blocks[i - 1].out_off + blocks[i - 1].isize))
             return fail(PSSBAM_EINVAL, "blocks[%u]: blocks must be in file order with contiguous out_off", i);
     }
-    if (first_record_offset && !(e->feed_fresh && e->feed[0].blocks.empty() && e->feed[1].blocks.empty()))
+    const bool assembling = e->cur_feed >= 0 && !e->feed[(size_t)e->cur_feed]->blocks.empty();
+    if (first_record_offset && !(e->feed_fresh && !assembling))
         return fail(PSSBAM_ESTATE, "first_record_offset only makes sense for the first blocks of a stream (after create / reset)");
     if (first_record_offset) e->feed_skip = first_record_offset;
     if (comp_bytes > e->feed_comp_cap / 2) return fail(PSSBAM_EINVAL, "chunk of %llu compressed bytes is too large", (unsigned long long)comp_bytes);
@@ -483,12 +616,37 @@ extern "C" int pssbam_engine_submit_bgzf(pssbam_engine *e, const void *comp, uin
         HIP_TRY(hipMalloc(&e->d_feed_tail, sizeof(uint64_t)));
         HIP_TRY(hipMemsetAsync(e->d_feed_tail, 0, sizeof(uint64_t), e->stream));
     }
+    // All or nothing: while the tallies are put off a slot may be unobtainable (PSSBAM_EBUSY) -- find that out before
+    // the first block of this chunk is taken.  A chunk spills over into at most one more super-batch (<= 1 GiB against
+    // 4.3 GB); with tiny test super-batches it may need more, which then go past the budget rather than fail half-way.
+    if (!feed_engine_ready(e)) {
+        bool fits = false;
+        if (e->cur_feed >= 0) {
+            const FeedAcc &cur = *e->feed[(size_t)e->cur_feed];
+            const uint64_t used = std::max<uint64_t>(cur.out_used, FEED_GAP);
+            fits = cur.blocks.size() + n_blocks < e->feed_block_target && used + out_bytes + 8192 <= FEED_GAP + e->feed_out_target &&
+                   cur.comp_used + comp_bytes + 64 <= e->feed_comp_cap;
+        }
+        if (!fits && e->spare_feed < 0) {
+            rc = feed_acquire(e, &e->spare_feed, false);
+            if (rc) return rc;
+        }
+    }
     hipStream_t cs = (e->ticket_seq & 1u) ? e->copy_stream2 : e->copy_stream;
     uint32_t b0 = 0;
     while (b0 < n_blocks) {
-        FeedAcc &cur = e->feed[e->cur_feed];
-        // (the first super-batch of a run is cut at a round of blocks / a third of the bytes, so the device starts earlier)
-        const bool first = e->inflated_bytes == 0 && !e->feed[e->cur_feed ^ 1].busy;
+        if (e->cur_feed < 0) {
+            if (e->spare_feed >= 0) { e->cur_feed = e->spare_feed; e->spare_feed = -1; }
+            else if ((rc = feed_acquire(e, &e->cur_feed, true))) { e->cur_feed = -1; return rc; }
+            FeedAcc &n = *e->feed[(size_t)e->cur_feed];
+            n.blocks.clear();
+            n.sub_first.clear();
+            n.comp_used = n.sub_bytes = 0;
+            n.out_used = FEED_GAP;
+        }
+        FeedAcc &cur = *e->feed[(size_t)e->cur_feed];
+        // (the first super-batch of a stream is cut at half a round of blocks / a third of the bytes, so the device starts earlier)
+        const bool first = e->flush_seq == 0;
         const uint64_t byte_target = first ? e->feed_out_target / 3 : e->feed_out_target;
         const uint64_t block_target = e->feed_block_target == 0xFFFFFFFFull ? 0xFFFFFFFFull
                                       : first ? (uint64_t)e->n_cu * 64ull * pssbam::INF_WAVES_PER_CU / 2ull   // half a round: the device starts early
@@ -497,8 +655,8 @@ extern "C" int pssbam_engine_submit_bgzf(pssbam_engine *e, const void *comp, uin
         uint32_t b1 = b0;
         const uint64_t comp0 = blocks[b0].in_off & ~15ull, out0 = blocks[b0].out_off;
         while (b1 < n_blocks && cur.blocks.size() + (b1 - b0) < block_target &&
-               cur.out_used + (blocks[b1].out_off + blocks[b1].isize - out0) + 512 <= byte_target + (1ull << 30) &&
-               std::max<uint64_t>(cur.out_used, FEED_GAP) + (blocks[b1].out_off + blocks[b1].isize - out0) + 8192 <= std::max<uint64_t>(cur.out_cap, e->feed_out_target + FEED_OUT_SLACK) &&
+               cur.out_used - FEED_GAP + (blocks[b1].out_off + blocks[b1].isize - out0) <= byte_target + FEED_OVERSHOOT &&
+               cur.out_used + (blocks[b1].out_off + blocks[b1].isize - out0) + 8192 <= cur.out_cap &&
                cur.comp_used + (blocks[b1].in_off + blocks[b1].in_len - comp0) + 64 <= e->feed_comp_cap)
             b1++;
         if (b1 == b0) {
@@ -510,7 +668,7 @@ extern "C" int pssbam_engine_submit_bgzf(pssbam_engine *e, const void *comp, uin
         rc = feed_append(e, (const uint8_t *)comp, blocks, b0, b1, cs);
         if (rc) return rc;
         b0 = b1;
-        if (e->feed[e->cur_feed].blocks.size() >= block_target || e->feed[e->cur_feed].out_used >= byte_target) {
+        if (cur.blocks.size() >= block_target || cur.out_used - FEED_GAP >= byte_target) {
             rc = feed_flush(e);
             if (rc) return rc;
         }
@@ -582,7 +740,9 @@ extern "C" int pssbam_engine_feed_status(pssbam_engine *e, uint32_t *flags, doub
     }
     e->inflate_events.clear();
     if (getenv("PSSBAM_STATS"))
-        fprintf(stderr, "[pssbam] engine feed: buffer allocation %.3f, waiting for a busy super-batch %.3f, flush (block table + launches) %.3f s\n",
+        fprintf(stderr, "[pssbam] engine feed: %llu super-batches in %zu slots (%llu allocated here), %llu tally launches put off until the genome was set; "
+                        "buffer allocation %.3f, waiting for a busy slot %.3f, flush (block table + launches) %.3f s\n",
+                (unsigned long long)e->flush_seq, e->feed.size(), (unsigned long long)e->feed_slots_allocated, (unsigned long long)e->feed_deferred_launches,
                 e->feed_t_alloc, e->feed_t_wait_busy, e->feed_t_flush);
     if (flags) *flags = f;
     if (inflate_ms) *inflate_ms = e->inflate_ms;

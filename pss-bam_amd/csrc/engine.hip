@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <map>
 #include <string>
 #include <memory>
 #include <mutex>
@@ -79,9 +80,13 @@ struct Slot {  // one in-flight host-submitted block
     uint64_t ticket = 0;      // the submit that last used the slot
 };
 
-// per super-batch: output of two rounds of the inflate kernel's 81 920 lanes (2 x 5.35 GB), and room for its compressed bytes
-static constexpr uint64_t FEED_OUT_TARGET = 10800ull << 20, FEED_COMP_CAP = 2ull << 30, FEED_OUT_SLACK = (1ull << 30) + (64ull << 20),
+// per super-batch: the output of ONE round of the inflate kernel's 65 536 lanes (a block per lane: 4.28 GB at htslib's
+// 65 280-byte blocks) and room for its compressed bytes.  Super-batches live in a ring of slots that grows while the tally
+// launches wait for the genome (pssbam_engine_feed_open) and is three deep otherwise.
+static constexpr uint64_t FEED_OUT_TARGET = 4400ull << 20, FEED_COMP_CAP = 2ull << 30, FEED_OUT_SLACK = 160ull << 20,
+                          FEED_OVERSHOOT = 64ull << 20,   // a submit may run this far past the target before the super-batch is cut
                           FEED_GAP = 16ull << 20;   // room in front of a super-batch's data for the record the previous one ended in
+static constexpr int FEED_SLOTS_READY = 3, FEED_SLOTS_MAX = 40;
 
 struct FeedAcc {  // one super-batch of compressed blocks: assembled chunk by chunk, then inflated in ONE launch
     uint8_t *d_comp = nullptr;      // compressed bytes of the chunks, back to back (each 16-byte aligned)
@@ -105,8 +110,40 @@ struct FeedAcc {  // one super-batch of compressed blocks: assembled chunk by ch
     size_t nrecs_cap = 0;
     uint64_t *d_chain = nullptr;             // [0] where this super-batch's chain starts, [1] where its tail starts
     hipEvent_t consumed = nullptr, copies_done = nullptr, copies_done2 = nullptr;
-    bool busy = false;
+    bool busy = false;                       // flushed; its buffers are in use until `consumed`
+    bool held = false;                       // ... and its tally launches still wait for the genome (no `consumed` yet)
+    uint64_t flush_seq = 0;                  // order of the flushes (the oldest busy slot frees first)
 };
+
+struct DeferredTally {   // a tally launch that waits for set_genome + set_references (pssbam_engine_feed_open)
+    int slot;
+    uint64_t sub_base, sub_len, offs_at;
+    uint32_t n_bound, k;
+    uint64_t sample_off;
+    bool last_of_slot;
+};
+
+// Host ranges page-locked for genome uploads, shared by the engines of a process (one engine per GPU uploads the same
+// contigs): registered once, released when the last upload that uses them has completed.
+namespace {
+struct PinEntry { size_t len; int refs; };
+std::map<const void *, PinEntry> g_pins;
+std::mutex g_pins_mu;
+bool pin_acquire(const void *p, size_t len) {
+    std::lock_guard<std::mutex> lk(g_pins_mu);
+    auto it = g_pins.find(p);
+    if (it != g_pins.end()) { it->second.refs++; return true; }
+    if (hipHostRegister((void *)p, len, hipHostRegisterPortable) != hipSuccess) { (void)hipGetLastError(); return false; }
+    g_pins[p] = PinEntry{len, 1};
+    return true;
+}
+void pin_release(const void *p) {
+    std::lock_guard<std::mutex> lk(g_pins_mu);
+    auto it = g_pins.find(p);
+    if (it == g_pins.end()) return;
+    if (--it->second.refs == 0) { (void)hipHostUnregister((void *)p); g_pins.erase(it); }
+}
+}  // namespace
 
 struct pssbam_engine {
     pssbam_config cfg{};
@@ -115,6 +152,11 @@ struct pssbam_engine {
     int device = 0;
     int n_cu = 0;
     hipStream_t stream = nullptr, copy_stream = nullptr, copy_stream2 = nullptr;
+    hipStream_t genome_stream = nullptr;   // genome upload + encode + pack: beside whatever the engine's stream runs
+    hipEvent_t genome_ready = nullptr;
+    bool genome_wait_pending = false;      // the next tally launch makes the engine's stream wait for genome_ready
+    std::vector<const void *> genome_pins; // host contigs page-locked for an upload still in flight
+    std::vector<void *> retired;           // device buffers replaced while kernels might still read them: freed at destroy
     hipEvent_t copied2 = nullptr;   // second half of a split H2D copy
     bool own_stream = false;
 
@@ -146,10 +188,17 @@ struct pssbam_engine {
     double h2d_ms = 0.0;      // summed H2D copy durations (events on the copy stream)
     uint64_t h2d_bytes = 0;
     // device-side inflate feed
-    FeedAcc feed[2];
-    int cur_feed = 0;
+    std::vector<FeedAcc *> feed;       // ring of super-batch slots
+    int cur_feed = -1, spare_feed = -1; // slot being assembled; slot acquired ahead for a submit that will spill over
+    uint64_t flush_seq = 0;
+    bool feed_opened = false;          // pssbam_engine_feed_open: submit_bgzf may precede set_genome / set_references
+    int32_t feed_n_ref = 0;            // ... with this many references in the BAM header
+    uint64_t feed_mem_budget = 0;      // device bytes the ring may take while tallies are deferred (0: not worked out yet)
+    std::vector<DeferredTally> deferred;
+    uint8_t *d_carry = nullptr;        // the partial record a super-batch ended with, on its way into the next slot's gap
     uint64_t feed_out_target = FEED_OUT_TARGET, feed_comp_cap = FEED_COMP_CAP;   // per super-batch
     double feed_t_alloc = 0, feed_t_wait_busy = 0, feed_t_flush = 0;   // host seconds inside the feed (PSSBAM_STATS)
+    uint64_t feed_slots_allocated = 0, feed_deferred_launches = 0;
     uint64_t feed_block_target = 0;   // blocks per super-batch: a whole number of rounds of the inflate kernel's lanes
     std::vector<std::pair<uint64_t, hipEvent_t>> feed_copies;             // (ticket, copy-complete event) of submits
     std::vector<hipEvent_t> feed_event_pool;
@@ -242,6 +291,8 @@ extern "C" int pssbam_engine_create(const pssbam_config *cfg, pssbam_engine **ou
     HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&e->copy_stream2, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&e->genome_stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&e->genome_ready, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&e->copied2, hipEventDisableTiming));
     e->own_stream = true;
     HIP_TRY(hipEventCreate(&e->t_begin));
@@ -289,7 +340,11 @@ extern "C" void pssbam_engine_destroy(pssbam_engine *e) {
         if (s.copy_begin) (void)hipEventDestroy(s.copy_begin);
         if (s.consumed) (void)hipEventDestroy(s.consumed);
     }
-    for (FeedAcc &s : e->feed) {
+    if (e->genome_stream) (void)hipStreamSynchronize(e->genome_stream);
+    for (const void *p : e->genome_pins) pin_release(p);
+    e->genome_pins.clear();
+    for (FeedAcc *sp : e->feed) {
+        FeedAcc &s = *sp;
         void *ptrs[] = {s.d_comp, s.d_blocks, s.d_a, s.d_e, s.d_last, s.d_nexta, s.d_n, s.d_counts, s.d_base, s.d_out, s.d_offs, s.d_nrecs, s.d_chain};
         for (void *q : ptrs)
             if (q) (void)hipFree(q);
@@ -297,7 +352,11 @@ extern "C" void pssbam_engine_destroy(pssbam_engine *e) {
         if (s.consumed) (void)hipEventDestroy(s.consumed);
         if (s.copies_done) (void)hipEventDestroy(s.copies_done);
         if (s.copies_done2) (void)hipEventDestroy(s.copies_done2);
+        delete sp;
     }
+    e->feed.clear();
+    if (e->d_carry) (void)hipFree(e->d_carry);
+    for (void *q : e->retired) (void)hipFree(q);
     if (e->d_feed_tail) (void)hipFree(e->d_feed_tail);
     for (auto &p : e->feed_copies) (void)hipEventDestroy(p.second);
     for (hipEvent_t ev : e->feed_event_pool) (void)hipEventDestroy(ev);
@@ -316,6 +375,8 @@ extern "C" void pssbam_engine_destroy(pssbam_engine *e) {
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
     if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
     if (e->copy_stream2) (void)hipStreamDestroy(e->copy_stream2);
+    if (e->genome_stream) (void)hipStreamDestroy(e->genome_stream);
+    if (e->genome_ready) (void)hipEventDestroy(e->genome_ready);
     if (e->copied2) (void)hipEventDestroy(e->copied2);
     delete e;
 }
@@ -335,12 +396,27 @@ extern "C" int pssbam_engine_set_stream(pssbam_engine *e, void *hip_stream) {
 // --------------------------------------------------------------------------------------
 static constexpr uint64_t CONTIG_ALIGN = 256, CONTIG_PAD = 256;
 
-extern "C" int pssbam_engine_set_genome_arrays(pssbam_engine *e, size_t n, const char *const *ids,
-                                               const uint8_t *const *seqs, const uint64_t *lens,
-                                               int seqs_on_device) {
+static hipEvent_t take_event(pssbam_engine *e);
+static int feed_resume(pssbam_engine *e);
+
+// The upload still in flight (if any) has completed: its page locks go back.
+static int genome_settle(pssbam_engine *e) {
+    if (e->genome_pins.empty()) return PSSBAM_OK;
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipEventSynchronize(e->genome_ready));
+    for (const void *p : e->genome_pins) pin_release(p);
+    e->genome_pins.clear();
+    return PSSBAM_OK;
+}
+
+// Lays the contigs out, allocates, and ENQUEUES copies + encode + 4-bit pack on the genome stream; tally launches wait
+// for genome_ready on the device.  Nothing here waits for the engine's stream (which may be busy inflating).
+static int genome_upload(pssbam_engine *e, size_t n, const char *const *ids, const uint8_t *const *seqs, const uint64_t *lens,
+                         int seqs_on_device) {
     if (!e || (n && (!ids || !seqs || !lens))) return fail(PSSBAM_EINVAL, "null argument");
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    int rc = genome_settle(e);
+    if (rc) return rc;
     // sorted view, as init_genome leaves Genome.seqs (fasta-genome-io.c:236)
     std::vector<size_t> order(n);
     for (size_t i = 0; i < n; i++) order[i] = i;
@@ -356,32 +432,39 @@ extern "C" int pssbam_engine_set_genome_arrays(pssbam_engine *e, size_t n, const
         len[k] = (uint32_t)lens[order[k]];
         total += ((uint64_t)len[k] + CONTIG_PAD + CONTIG_ALIGN - 1) / CONTIG_ALIGN * CONTIG_ALIGN;
     }
-    if (e->d_genome) { HIP_TRY(hipFree(e->d_genome)); e->d_genome = nullptr; }
+    if (e->d_genome) {   // a genome is being replaced: kernels queued on the engine's stream may still read the old one
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        HIP_TRY(hipFree(e->d_genome));
+        e->d_genome = nullptr;
+        if (e->d_genome4) { HIP_TRY(hipFree(e->d_genome4)); e->d_genome4 = nullptr; }
+    }
     HIP_TRY(hipMalloc(&e->d_genome, total));
+    hipStream_t gs = e->genome_stream;
+    if (seqs_on_device) {   // the caller's device arrays were written on ITS stream (the engine's, after set_stream)
+        hipEvent_t ev = take_event(e);
+        if (!ev) return fail(PSSBAM_EHIP, "hipEventCreate failed");
+        HIP_TRY(hipEventRecord(ev, e->stream));
+        HIP_TRY(hipStreamWaitEvent(gs, ev, 0));
+        e->event_pool.push_back(ev);
+    }
     // padding = raw NUL, like the terminator the reference finds at index len (fragkon.c odd-k
     // windows); the encode pass below turns it into the stored form of NUL ("not a base")
-    HIP_TRY(hipMemsetAsync(e->d_genome, 0, total, e->stream));
+    HIP_TRY(hipMemsetAsync(e->d_genome, 0, total, gs));
     // Host contigs: large ones are page-locked for the copy (cheap when the loader put them on
     // transparent huge pages: 2 MiB per pin instead of 4 KiB), which turns a staged pageable copy into
-    // one DMA at link speed; if the lock is refused the plain copy below does the job.
-    std::vector<const void *> locked;
+    // one DMA at link speed; if the lock is refused the plain copy below does the job.  The locks are
+    // shared by the engines of the process and go back when the last upload has completed.
     const bool try_lock = !seqs_on_device && !getenv("PSSBAM_NO_PIN");
     for (size_t k = 0; k < n; k++) {
         if (!len[k]) continue;
         const void *src = seqs[order[k]];
-        if (try_lock && len[k] >= (32u << 20) && hipHostRegister((void *)src, len[k], hipHostRegisterDefault) == hipSuccess) locked.push_back(src);
-        else (void)hipGetLastError();
+        if (try_lock && len[k] >= (32u << 20) && pin_acquire(src, len[k])) e->genome_pins.push_back(src);
         HIP_TRY(hipMemcpyAsync(e->d_genome + start[k], src, len[k],
-                               seqs_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, e->stream));
-    }
-    if (!locked.empty()) {
-        HIP_TRY(hipStreamSynchronize(e->stream));
-        for (const void *p : locked) (void)hipHostUnregister((void *)p);
+                               seqs_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, gs));
     }
     // raw bytes (and NUL padding) are in place: one pass folds case and applies enc_byte to all
-    hipLaunchKernelGGL(encode_genome_kernel, dim3(4096), dim3(256), 0, e->stream, e->d_genome, total / 16);
+    hipLaunchKernelGGL(encode_genome_kernel, dim3(4096), dim3(256), 0, gs, e->d_genome, total / 16);
     HIP_TRY(hipGetLastError());
-    if (e->d_genome4) { HIP_TRY(hipFree(e->d_genome4)); e->d_genome4 = nullptr; }
     {
         // 4 bits per base for the tiled kernel's windows: A C G T, or "other" with its -U / -D membership
         CtxSets sets;
@@ -392,13 +475,14 @@ extern "C" int pssbam_engine_set_genome_arrays(pssbam_engine *e, size_t n, const
             e->acgt_ctx |= (((sets.up[0] >> v) & 1u) << (2 * v)) | (((sets.down[0] >> v) & 1u) << (2 * v + 1));
         const uint64_t n_out = total / 8, slack = 16;
         HIP_TRY(hipMalloc(&e->d_genome4, (n_out + slack) * sizeof(uint32_t)));
-        HIP_TRY(hipMemsetAsync(e->d_genome4 + n_out, 0x44, slack * sizeof(uint32_t), e->stream));
-        hipLaunchKernelGGL(pack_genome4_kernel, dim3(4096), dim3(256), 0, e->stream, e->d_genome, e->d_genome4, n_out, sets);
+        HIP_TRY(hipMemsetAsync(e->d_genome4 + n_out, 0x44, slack * sizeof(uint32_t), gs));
+        hipLaunchKernelGGL(pack_genome4_kernel, dim3(4096), dim3(256), 0, gs, e->d_genome, e->d_genome4, n_out, sets);
         HIP_TRY(hipGetLastError());
     }
+    HIP_TRY(hipEventRecord(e->genome_ready, gs));
+    e->genome_wait_pending = true;
     e->contig_start.assign(start.begin(), start.begin() + n);
     e->contig_len.assign(len.begin(), len.begin() + n);
-    HIP_TRY(hipStreamSynchronize(e->stream));
     e->genome_bytes = total;
     e->contig_ids.clear();
     for (size_t k = 0; k < n; k++) e->contig_ids.emplace_back(ids[order[k]]);
@@ -412,7 +496,16 @@ extern "C" int pssbam_engine_set_genome_arrays(pssbam_engine *e, size_t n, const
     return PSSBAM_OK;
 }
 
-extern "C" int pssbam_engine_set_genome(pssbam_engine *e, const struct genome *g) {
+extern "C" int pssbam_engine_set_genome_arrays(pssbam_engine *e, size_t n, const char *const *ids,
+                                               const uint8_t *const *seqs, const uint64_t *lens,
+                                               int seqs_on_device) {
+    int rc = genome_upload(e, n, ids, seqs, lens, seqs_on_device);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(e->genome_stream));   // the caller may release its arrays when this returns
+    return genome_settle(e);
+}
+
+static int genome_from_struct(pssbam_engine *e, const struct genome *g, bool wait) {
     if (!e || !g) return fail(PSSBAM_EINVAL, "null argument");
     std::vector<const char *> ids(g->n_seqs);
     std::vector<const uint8_t *> seqs(g->n_seqs);
@@ -422,7 +515,21 @@ extern "C" int pssbam_engine_set_genome(pssbam_engine *e, const struct genome *g
         seqs[i] = (const uint8_t *)g->seqs[i]->seq;
         lens[i] = g->seqs[i]->len;
     }
-    return pssbam_engine_set_genome_arrays(e, g->n_seqs, ids.data(), seqs.data(), lens.data(), 0);
+    return wait ? pssbam_engine_set_genome_arrays(e, g->n_seqs, ids.data(), seqs.data(), lens.data(), 0)
+                : genome_upload(e, g->n_seqs, ids.data(), seqs.data(), lens.data(), 0);
+}
+
+extern "C" int pssbam_engine_set_genome(pssbam_engine *e, const struct genome *g) { return genome_from_struct(e, g, true); }
+
+// Same, but returns as soon as the upload is enqueued: the Genome must stay untouched until pssbam_engine_genome_wait,
+// _sync or _finish has returned.  Lets one host thread start the uploads of several GPUs at once.
+extern "C" int pssbam_engine_set_genome_async(pssbam_engine *e, const struct genome *g) { return genome_from_struct(e, g, false); }
+
+extern "C" int pssbam_engine_genome_wait(pssbam_engine *e) {
+    if (!e) return fail(PSSBAM_EINVAL, "null engine");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->genome_stream));
+    return genome_settle(e);
 }
 
 extern "C" int pssbam_engine_set_references(pssbam_engine *e, int32_t n_ref, const char *const *names) {
@@ -447,13 +554,20 @@ extern "C" int pssbam_engine_set_references(pssbam_engine *e, int32_t n_ref, con
         }
     }
     fill((size_t)n_ref, e->star_contig);
-    HIP_TRY(hipStreamSynchronize(e->stream));
-    if (e->d_ref_info) { HIP_TRY(hipFree(e->d_ref_info)); e->d_ref_info = nullptr; }
+    if (e->feed_opened && !e->deferred.empty() && n_ref != e->feed_n_ref)
+        return fail(PSSBAM_ESTATE, "pssbam_engine_feed_open announced %d references, set_references brings %d", e->feed_n_ref, n_ref);
+    // a table that is being REPLACED (SAM text: the list grows as new RNAMEs show up) may still be read by queued
+    // kernels; the first one cannot be, so nothing waits for the engine's stream then
+    if (e->d_ref_info) {
+        if (e->have_refs) HIP_TRY(hipStreamSynchronize(e->stream));
+        HIP_TRY(hipFree(e->d_ref_info));
+        e->d_ref_info = nullptr;
+    }
     HIP_TRY(hipMalloc(&e->d_ref_info, ((size_t)n_ref + 1) * sizeof(uint4)));
     HIP_TRY(hipMemcpy(e->d_ref_info, info.data(), ((size_t)n_ref + 1) * sizeof(uint4), hipMemcpyHostToDevice));
     e->n_ref = n_ref;
     e->have_refs = true;
-    return PSSBAM_OK;
+    return feed_resume(e);   // super-batches inflated ahead of the genome are tallied now
 }
 
 // --------------------------------------------------------------------------------------
@@ -586,6 +700,10 @@ static int launch_tally(pssbam_engine *e, const uint8_t *d_recs, uint64_t nbytes
     const uint32_t n_passes = do_pss ? (e->rows + TILED_ROWS - 1) / TILED_ROWS : 1u;
     if (kernel == PSSBAM_KERNEL_AUTO) kernel = PSSBAM_KERNEL_TILED;
 
+    if (e->genome_wait_pending) {   // the upload runs on its own stream
+        HIP_TRY(hipStreamWaitEvent(e->stream, e->genome_ready, 0));
+        e->genome_wait_pending = false;
+    }
     hipEvent_t ev0 = take_event(e), ev1 = take_event(e);
     if (!ev0 || !ev1) return fail(PSSBAM_EHIP, "hipEventCreate failed");
     HIP_TRY(hipEventRecord(ev0, e->stream));
@@ -874,7 +992,13 @@ extern "C" int pssbam_engine_sync(pssbam_engine *e) {
     }
     HIP_TRY(hipStreamSynchronize(e->copy_stream2));
     HIP_TRY(hipStreamSynchronize(e->copy_stream));
+    HIP_TRY(hipStreamSynchronize(e->genome_stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
+    const int rc = genome_settle(e);
+    if (rc) return rc;
+    // (the streams are quiet either way: the caller's buffers are free)
+    if (!e->deferred.empty())
+        return fail(PSSBAM_ESTATE, "compressed blocks were fed (pssbam_engine_feed_open) but set_genome / set_references never followed");
     return PSSBAM_OK;
 }
 
@@ -899,6 +1023,15 @@ extern "C" int pssbam_engine_reset(pssbam_engine *e) {
     HIP_TRY(hipSetDevice(e->device));
     e->feed_fresh = true;   // a compressed stream fed from here on starts a new record chain
     e->feed_skip = 0;
+    if (!e->deferred.empty()) {   // inflated ahead of the genome and now given up: the slots go back once their kernels have run
+        e->deferred.clear();
+        for (FeedAcc *sp : e->feed)
+            if (sp->held) {
+                sp->held = false;
+                if (!sp->consumed) HIP_TRY(hipEventCreateWithFlags(&sp->consumed, hipEventDisableTiming));
+                HIP_TRY(hipEventRecord(sp->consumed, e->stream));
+            }
+    }
     if (e->d_feed_tail) HIP_TRY(hipMemsetAsync(e->d_feed_tail, 0, sizeof(uint64_t), e->stream));
     if (e->d_feed_flags) HIP_TRY(hipMemsetAsync(e->d_feed_flags, 0, sizeof(uint32_t), e->stream));
     HIP_TRY(hipMemsetAsync(e->d_counters, 0, e->n_counters * sizeof(unsigned long long), e->stream));
@@ -917,6 +1050,10 @@ extern "C" int pssbam_engine_genome_kmer_count(pssbam_engine *e, int klen, uint6
     if (klen < 1 || klen > PSSBAM_MAX_KLEN) return fail(PSSBAM_EINVAL, "klen %d outside the device range 1..%d", klen, PSSBAM_MAX_KLEN);
     if (!e->d_genome) return fail(PSSBAM_ESTATE, "set_genome has not been called");
     HIP_TRY(hipSetDevice(e->device));
+    if (e->genome_wait_pending) {
+        HIP_TRY(hipStreamWaitEvent(e->stream, e->genome_ready, 0));
+        e->genome_wait_pending = false;
+    }
     const size_t nb = (size_t)1 << (2 * klen);
     unsigned long long *d_bins = nullptr;
     HIP_TRY(hipMalloc(&d_bins, nb * sizeof(unsigned long long)));

@@ -1010,16 +1010,24 @@ __global__ void __launch_bounds__(256) bgzf_chain_write(const uint8_t *out, cons
     }
 }
 
-// the partial record a super-batch ends with goes in front of the next super-batch's data
-__global__ void __launch_bounds__(256) bgzf_chain_carry(const uint8_t *src_out, const uint64_t *tail_start, uint64_t data_end, uint8_t *dst_out,
-                                                        uint64_t gap, uint64_t *next_first_start, uint64_t *tail_len_out, uint32_t *flags) {
+// The partial record a super-batch ends with travels to the next one through a small buffer of its own (the next
+// super-batch's slot is not known -- maybe not even allocated -- when this one is flushed): _out copies the tail
+// [*tail_start, data_end) there, _in puts it in front of the next slot's data, whose block 0 starts its walk there.
+__global__ void __launch_bounds__(256) bgzf_chain_carry_out(const uint8_t *src_out, const uint64_t *tail_start, uint64_t data_end, uint8_t *carry,
+                                                            uint64_t gap, uint64_t *tail_len_out, uint32_t *flags) {
     const uint64_t from = *tail_start, len = data_end > from ? data_end - from : 0ull;
     if (len > gap) {
-        if (threadIdx.x == 0) { atomicOr(flags, FEED_RAGGED); *next_first_start = gap; *tail_len_out = 0; }
+        if (threadIdx.x == 0) { atomicOr(flags, FEED_RAGGED); *tail_len_out = 0; }
         return;
     }
-    for (uint64_t i = threadIdx.x; i < len; i += blockDim.x) dst_out[gap - len + i] = src_out[from + i];
-    if (threadIdx.x == 0) { *next_first_start = gap - len; *tail_len_out = len; }
+    for (uint64_t i = threadIdx.x; i < len; i += blockDim.x) carry[i] = src_out[from + i];
+    if (threadIdx.x == 0) *tail_len_out = len;
+}
+__global__ void __launch_bounds__(256) bgzf_chain_carry_in(const uint8_t *carry, const uint64_t *tail_len, uint8_t *dst_out, uint64_t gap,
+                                                           uint64_t *first_start) {
+    const uint64_t len = min(*tail_len, gap);
+    for (uint64_t i = threadIdx.x; i < len; i += blockDim.x) dst_out[gap - len + i] = carry[i];
+    if (threadIdx.x == 0) *first_start = gap - len;
 }
 
 // the caller declares that the next blocks do not continue the stream fed so far: a partial record

@@ -230,9 +230,9 @@ static feed_loader *g_pre = NULL;
 void device_feed_prefetch(const char *path)
 {
     const char *ng = getenv("PSSBAM_NGPU");
-    if (g_pre || !device_feed_enabled() || (ng && atoi(ng) > 1)) return;   /* (slot count depends on the engines: one GPU only) */
-    int not_regular;
-    g_pre = loader_open(path, 1, &not_regular);
+    if (g_pre || !device_feed_enabled()) return;
+    int not_regular, n = ng ? atoi(ng) : 1;   /* (the HIP runtime is not up yet: the count asked for sizes the slots) */
+    g_pre = loader_open(path, n < 1 ? 1 : n > 64 ? 64 : n, &not_regular);
 }
 
 void device_feed_prefetch_pin(void) { loader_pin(g_pre); }   /* needs the HIP runtime: called by the warm-up thread */
@@ -244,13 +244,14 @@ void device_feed_prefetch_cancel(void)
 }
 
 int run_device_feed(pssbam_engine *const *eng, int n_gpus, const char *path, size_t header_bytes, int run, int verbose,
-                    device_feed_stats *fs)
+                    device_feed_stats *fs, const feed_gate *gate)
 {
     int rc = -1;
     pssbam_bgzf_block *blocks = NULL, *grp = NULL;
     feed_loader *F = NULL;
     memset(fs, 0, sizeof *fs);
-    if (g_pre && n_gpus == 1 && strcmp(g_pre->path, path) == 0) {
+    int gate_open = gate == NULL;   /* genome + references are on the engines */
+    if (g_pre && strcmp(g_pre->path, path) == 0) {
         F = g_pre;
         g_pre = NULL;
     } else {
@@ -303,7 +304,8 @@ int run_device_feed(pssbam_engine *const *eng, int n_gpus, const char *path, siz
         fifo_len--;                                                                                       \
     } while (0)
 
-    double t_wait_load = 0, t_wait_copy = 0, t_scan = 0, t_submit = 0;
+    double t_wait_load = 0, t_wait_copy = 0, t_scan = 0, t_submit = 0, t_gate = 0;
+    uint64_t n_submits_ahead = 0;   /* submits that went in before the genome was set */
     long n_prescanned = 0;
     size_t pos = 0;                /* file offset of the next BGZF block */
     size_t skip = header_bytes;    /* inflated bytes still to skip in front of the first record */
@@ -369,13 +371,27 @@ int run_device_feed(pssbam_engine *const *eng, int n_gpus, const char *path, siz
                     last_g = g;
                 }
                 uint64_t ticket = 0;
+                if (!gate_open) {   /* has the genome arrived?  (sets it on the engines, which then tally what they inflated ahead) */
+                    const int r = gate->poll(gate->ctx, 0);
+                    if (r < 0) goto done;
+                    gate_open = r > 0;
+                }
                 const double tsub = mono_s();
-                if (pssbam_engine_submit_bgzf(eng[g], s->buf + chunk_rel + base_in, end_in - base_in, grp, (uint32_t)(j - i), (uint32_t)skip,
-                                              &ticket)) {
+                int src = pssbam_engine_submit_bgzf(eng[g], s->buf + chunk_rel + base_in, end_in - base_in, grp, (uint32_t)(j - i), (uint32_t)skip,
+                                                    &ticket);
+                if (src == PSSBAM_EBUSY && !gate_open) {   /* every slot holds records that wait for the genome: so do we */
+                    const double tg = mono_s();
+                    if (gate->poll(gate->ctx, 1) <= 0) goto done;
+                    t_gate += mono_s() - tg;
+                    gate_open = 1;
+                    src = pssbam_engine_submit_bgzf(eng[g], s->buf + chunk_rel + base_in, end_in - base_in, grp, (uint32_t)(j - i), (uint32_t)skip, &ticket);
+                }
+                if (src) {
                     fprintf(stderr, "Error: GPU engine: %s\n", pssbam_last_error());
                     goto done;
                 }
                 t_submit += mono_s() - tsub;
+                if (!gate_open) n_submits_ahead++;
                 skip = 0;
                 n_submits++;
                 fs->compressed_bytes += end_in - base_in;
@@ -399,6 +415,12 @@ int run_device_feed(pssbam_engine *const *eng, int n_gpus, const char *path, siz
     while (fifo_len > 0) RETIRE();
 #undef RETIRE
     if (pos != L->file_size) { fprintf(stderr, "Error: %s: truncated BGZF block at end of file\n", path); goto done; }
+    if (!gate_open) {   /* the whole file went in ahead of the genome */
+        const double tg = mono_s();
+        if (gate->poll(gate->ctx, 1) <= 0) goto done;
+        t_gate += mono_s() - tg;
+        gate_open = 1;
+    }
     fs->n_submits = n_submits;
     /* how the blocks fared: one word per engine */
     for (int g = 0; g < n_gpus; g++) {
@@ -424,8 +446,9 @@ int run_device_feed(pssbam_engine *const *eng, int n_gpus, const char *path, siz
                 fs->fallback ? "; records cross BGZF blocks -> host reader" : "");
     if (verbose)
         fprintf(stderr, "[pssbam] device feed, this thread: waiting for loaders %.3f, block-header walk %.3f (%ld of %ld windows walked by "
-                        "their loader), submit (incl. waiting for a free super-batch) %.3f, waiting for copies %.3f s\n", t_wait_load, t_scan,
-                n_prescanned, L->n_chunks, t_submit, t_wait_copy);
+                        "their loader), submit (incl. waiting for a free slot) %.3f, waiting for copies %.3f, waiting for the genome %.3f s "
+                        "(%llu of the submits went in ahead of it)\n", t_wait_load, t_scan,
+                n_prescanned, L->n_chunks, t_submit, t_wait_copy, t_gate, (unsigned long long)n_submits_ahead);
     rc = 0;
 done:
     if (rc) {   /* nothing may still read the staging slots */

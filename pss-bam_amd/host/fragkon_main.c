@@ -71,14 +71,6 @@ int main(int argc, char *argv[])
         fprintf(stderr, "    *** k is odd - counting %d bases outside %d bases inside of alignment.\n", klen / 2,
                 klen / 2 + 1);
     fprintf(stderr, "Reading genome sequence from: %s\n", fasta_fn);
-    frontend_warmup_start(bam_fn);   /* HIP start-up overlaps the FASTA load */
-    Genome *genome = init_genome(fasta_fn);
-    if (!genome) {
-        fprintf(stderr, "Error: Unable to load genome from %s.\n", fasta_fn);
-        exit(1);
-    }
-    fprintf(stderr, "Finished loading genome.\nCounting kmer contexts for: %s\n", bam_fn);
-
     pssbam_config cfg;
     memset(&cfg, 0, sizeof cfg);
     cfg.abi_version = PSSBAM_ABI_VERSION;
@@ -90,6 +82,15 @@ int main(int argc, char *argv[])
     cfg.kmer.merged_only = merged_only;
     cfg.device = 0;
     cfg.kernel = PSSBAM_KERNEL_AUTO;
+
+    /* HIP start-up, engines and the compressed BAM feed overlap the FASTA load (frontend.c) */
+    frontend_warmup_start(&cfg, bam_fn, fasta_fn);
+    Genome *genome = init_genome(fasta_fn);
+    if (!genome) {
+        fprintf(stderr, "Error: Unable to load genome from %s.\n", fasta_fn);
+        exit(1);
+    }
+    fprintf(stderr, "Finished loading genome.\nCounting kmer contexts for: %s\n", bam_fn);
 
     run_result res;
     frontend_fast_exit = getenv("PSSBAM_CLEAN_EXIT") == NULL;

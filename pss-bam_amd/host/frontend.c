@@ -13,6 +13,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
 #include <time.h>
 #include <unistd.h>
 
@@ -22,18 +23,109 @@
 
 int frontend_fast_exit = 0;
 
-/* start-up work that overlaps the caller's FASTA load: the BAM reader opened early (it starts
- * inflating its first batches at once), HIP runtime + device contexts, page-locking of the
- * reader's slots */
+/* Start-up work that overlaps the caller's FASTA load.  The reference is serial by construction -- load the
+ * genome, then loop over the alignments (pss-bam.c:751-783) -- but only the TALLY needs reference bases: a helper
+ * thread brings the HIP runtime up, creates the engines and runs the whole compressed feed (PCIe, inflate, CRC-32,
+ * record index: device_feed.c) while init_genome is still parsing.  run_tally() then posts the Genome; the helper
+ * uploads it to every engine at once (pssbam_engine_set_genome_async) and the super-batches inflated ahead of it
+ * are tallied.  For inputs the device feed does not take (SAM text, PSSBAM_DEVICE_INFLATE=0) the helper only warms
+ * the runtime up and page-locks the host reader's slots, as before. */
 static bam_reader *early_rd = NULL;
 static char early_path[4096];
 static int early_registered = 0, early_light = 0;
 static pthread_t warmup_thread;
 static int warmup_running = 0;
 
+static struct early_feed {
+    int want;                       /* engines + feed on the helper thread */
+    pssbam_config cfg;
+    char *up, *down, *rg;           /* the strings cfg points at */
+    uint64_t fasta_bytes;
+    pssbam_engine *eng[64];
+    int n_gpus, engines_ok, fed, feed_rc, genome_set, failed;
+    device_feed_stats dfs;
+    char err[600];
+    pthread_mutex_t mu;
+    pthread_cond_t cv;
+    Genome *genome;
+    int posted, abandon;
+    double t0, t_hip, t_engines, t_posted, t_genome_set, t_genome_set_dur, t_feed_end;
+} EF = {.mu = PTHREAD_MUTEX_INITIALIZER, .cv = PTHREAD_COND_INITIALIZER};
+
+/* device_feed.h feed_gate: 1 = genome and references are on every engine */
+static int early_gate(void *ctx, int block)
+{
+    (void)ctx;
+    pthread_mutex_lock(&EF.mu);
+    while (!EF.posted && !EF.abandon && block) pthread_cond_wait(&EF.cv, &EF.mu);
+    const int abandon = EF.abandon, posted = EF.posted;
+    Genome *genome = EF.genome;
+    pthread_mutex_unlock(&EF.mu);
+    if (abandon) return -1;
+    if (!posted) return 0;
+    if (!EF.genome_set) {
+        const double t = frontend_now_s();
+        const bam_header *h = bam_reader_header(early_rd);
+        /* every GPU's upload is enqueued before the first one is waited for: the links run side by side */
+        for (int g = 0; g < EF.n_gpus; g++)
+            if (pssbam_engine_set_genome_async(EF.eng[g], genome)) goto fail;
+        for (int g = 0; g < EF.n_gpus; g++)
+            if (pssbam_engine_set_references(EF.eng[g], h->n_ref, (const char *const *)h->ref_name)) goto fail;
+        EF.genome_set = 1;
+        EF.t_genome_set = frontend_now_s() - EF.t0;
+        EF.t_genome_set_dur = frontend_now_s() - t;
+    }
+    return 1;
+fail:
+    snprintf(EF.err, sizeof EF.err, "GPU engine: %s", pssbam_last_error());
+    EF.failed = 1;
+    return -1;
+}
+
+static int feed_run(int n_gpus);
+
+static void early_feed_main(void)
+{
+    const int n = env_gpu_count(); /* the first HIP call: runtime start-up happens here */
+    EF.t_hip = frontend_now_s() - EF.t0;
+    const bam_header *h = bam_reader_header(early_rd);
+    const int have = pssbam_device_count();
+    for (int g = 0; g < n; g++) {
+        pssbam_config c = EF.cfg;
+        c.device = have > 0 ? g % have : g;
+        if (pssbam_engine_create(&c, &EF.eng[g]) || pssbam_engine_feed_open(EF.eng[g], h->n_ref, EF.fasta_bytes)) {
+            snprintf(EF.err, sizeof EF.err, "GPU engine %d: %s", g, pssbam_last_error());
+            EF.failed = 1;
+            EF.n_gpus = g + (EF.eng[g] != NULL);
+            return;
+        }
+        EF.n_gpus = g + 1;
+    }
+    EF.engines_ok = 1;
+    EF.t_engines = frontend_now_s() - EF.t0;
+    { /* the light reader has inflated the file's first records on the host: the engines size their staged
+       * record prefix from them (no read-back from the device later) */
+        const uint8_t *r0;
+        const uint32_t *o0;
+        size_t nb0;
+        int slot0 = -1;
+        if (bam_reader_next_hold(early_rd, &r0, &o0, &nb0, &slot0) > 0)
+            for (int g = 0; g < n; g++) (void)pssbam_engine_hint_records(EF.eng[g], r0, nb0);
+        if (slot0 >= 0) bam_reader_release(early_rd, slot0);
+    }
+    const feed_gate gate = {early_gate, NULL};
+    EF.feed_rc = run_device_feed(EF.eng, n, early_path, bam_reader_header_bytes(early_rd), feed_run(n), getenv("PSSBAM_STATS") != NULL, &EF.dfs, &gate);
+    EF.fed = 1;
+    EF.t_feed_end = frontend_now_s() - EF.t0;
+}
+
 static void *warmup_main(void *arg)
 {
     (void)arg;
+    if (EF.want) {
+        early_feed_main();
+        return NULL;
+    }
     const int n = env_gpu_count(); /* the first HIP call: runtime start-up happens here */
     for (int g = 0; g < n; g++) (void)pssbam_warmup(g); /* failures surface in pssbam_engine_create */
     if (early_rd && early_light && !getenv("PSSBAM_OVERSUBSCRIBE"))
@@ -64,19 +156,46 @@ static int feed_slots(int n_gpus)
     return n_gpus > 1 ? n_gpus * feed_run(n_gpus) + 2 : 3;
 }
 
-void frontend_warmup_start(const char *aln_path)
+static char *dup_or_null(const char *p) { return p ? strdup(p) : NULL; }
+
+void frontend_warmup_start(const pssbam_config *cfg, const char *aln_path, const char *fasta_path)
 {
+    EF.t0 = frontend_now_s();
     if (aln_path && strlen(aln_path) < sizeof early_path && file_is_bam(aln_path) == 1) {
         char err[256];
         /* device feed: the reader is only asked for the BAM header (two threads, small batches) */
-        early_light = device_feed_enabled();
+        early_light = device_feed_enabled() && !(cfg && cfg->kernel == PSSBAM_KERNEL_SIMPLE);
         early_rd = early_light ? bam_reader_open_slots(aln_path, 2, (size_t)8 << 20, 3, err, sizeof err)
-                               : bam_reader_open_slots(aln_path, 0, 0, feed_slots(env_gpu_count()), err, sizeof err);
+                               : bam_reader_open_slots(aln_path, 0, 0, feed_slots(getenv("PSSBAM_NGPU") ? atoi(getenv("PSSBAM_NGPU")) : 1), err, sizeof err);
         /* (a failure is reported by run_tally's own open) */
         if (early_rd) strcpy(early_path, aln_path);
         if (early_rd && early_light) device_feed_prefetch(aln_path); /* its loader threads read the first windows meanwhile */
+        if (early_rd && early_light && cfg && !getenv("PSSBAM_NO_EARLY_FEED")) {
+            EF.want = 1;
+            EF.cfg = *cfg;
+            EF.cfg.pss.up_ctx = EF.up = dup_or_null(cfg->pss.up_ctx);
+            EF.cfg.pss.down_ctx = EF.down = dup_or_null(cfg->pss.down_ctx);
+            EF.cfg.read_group = EF.rg = dup_or_null(cfg->read_group);
+            struct stat sb;
+            EF.fasta_bytes = fasta_path && stat(fasta_path, &sb) == 0 ? (uint64_t)sb.st_size : 0;
+        }
     }
     warmup_running = pthread_create(&warmup_thread, NULL, warmup_main, NULL) == 0;
+    if (!warmup_running) EF.want = 0;
+}
+
+static int same_str(const char *a, const char *b) { return (!a && !b) || (a && b && strcmp(a, b) == 0); }
+
+static int same_config(const pssbam_config *a, const pssbam_config *b)
+{
+    return a->tally_mask == b->tally_mask && a->kernel == b->kernel && same_str(a->read_group, b->read_group) &&
+           (!(a->tally_mask & PSSBAM_TALLY_PSS) ||
+            (a->pss.region_len == b->pss.region_len && a->pss.min_read_len == b->pss.min_read_len && a->pss.max_read_len == b->pss.max_read_len &&
+             a->pss.min_mq == b->pss.min_mq && a->pss.merged_only == b->pss.merged_only && same_str(a->pss.up_ctx, b->pss.up_ctx) &&
+             same_str(a->pss.down_ctx, b->pss.down_ctx))) &&
+           (!(a->tally_mask & PSSBAM_TALLY_KMER) ||
+            (a->kmer.klen == b->kmer.klen && a->kmer.min_mq == b->kmer.min_mq && a->kmer.min_read_len == b->kmer.min_read_len &&
+             a->kmer.max_read_len == b->kmer.max_read_len && a->kmer.merged_only == b->kmer.merged_only));
 }
 
 void front_end_exit(int status)
@@ -84,6 +203,28 @@ void front_end_exit(int status)
     fflush(NULL);
     if (frontend_fast_exit) _exit(status);
     exit(status);
+}
+
+/* seconds since the process was created (exec + dynamic loading included): /proc/self/stat field 22 is the
+ * start time in clock ticks after boot (10 ms resolution); -1 if it cannot be read */
+double frontend_process_age_s(void)
+{
+    FILE *f = fopen("/proc/self/stat", "r");
+    if (!f) return -1.0;
+    char buf[2048];
+    const size_t n = fread(buf, 1, sizeof buf - 1, f);
+    fclose(f);
+    buf[n] = 0;
+    const char *p = strrchr(buf, ')'); /* (the command name may hold spaces) */
+    if (!p) return -1.0;
+    unsigned long long start = 0;
+    int field = 2;
+    for (p++; *p && field < 22; p++)
+        if (*p == ' ') field++;
+    if (field != 22 || sscanf(p, "%llu", &start) != 1) return -1.0;
+    struct timespec ts;
+    if (clock_gettime(CLOCK_BOOTTIME, &ts) != 0) return -1.0;
+    return ts.tv_sec + ts.tv_nsec * 1e-9 - (double)start / (double)sysconf(_SC_CLK_TCK);
 }
 
 double frontend_now_s(void)
@@ -138,15 +279,36 @@ int run_tally(const pssbam_config *cfg, Genome *genome, const char *aln_path, in
         fprintf(stderr, "Error: Unable to open %s.\n", aln_path);
         return -1;
     }
-    if (warmup_running) { /* HIP is needed from here on; the early reader's slots may be pinned by now */
+    device_feed_stats dfs;
+    memset(&dfs, 0, sizeof dfs);
+    int fed_on_device = 0, adopted = 0, light = 0;
+    int device_feed = is_bam && device_feed_enabled() && cfg->kernel != PSSBAM_KERNEL_SIMPLE;
+    if (warmup_running) { /* HIP is needed from here on; the helper thread may be feeding already */
+        const int mine = EF.want && is_bam && strcmp(early_path, aln_path) == 0 && same_config(cfg, &EF.cfg) && device_feed;
+        if (EF.want) {
+            pthread_mutex_lock(&EF.mu);
+            if (mine) { EF.genome = genome; EF.posted = 1; }
+            else EF.abandon = 1;
+            EF.t_posted = now_s() - EF.t0;
+            pthread_cond_broadcast(&EF.cv);
+            pthread_mutex_unlock(&EF.mu);
+        }
         pthread_join(warmup_thread, NULL);
         warmup_running = 0;
+        if (EF.want && mine && EF.engines_ok && !EF.failed) {
+            adopted = 1;
+            n_gpus = EF.n_gpus;
+            for (int g = 0; g < n_gpus; g++) eng[g] = EF.eng[g];
+        } else if (EF.want) { /* not this run's file / options, or the helper could not set up: start over below */
+            for (int g = 0; g < EF.n_gpus; g++)
+                if (EF.eng[g]) pssbam_engine_destroy(EF.eng[g]);
+            if (EF.failed && verbose) fprintf(stderr, "[pssbam] early feed not usable (%s): regular start\n", EF.err);
+        }
+        EF.want = 0;
     }
     /* BAM: inflate on the GPU (device_feed.c) unless switched off or the cross-check kernel is forced;
      * the host reader then only parses the header -- and takes over if the file's records cross BGZF
      * blocks */
-    int device_feed = is_bam && device_feed_enabled() && cfg->kernel != PSSBAM_KERNEL_SIMPLE;
-    int light = 0;
     if (is_bam && early_rd && strcmp(early_path, aln_path) == 0) {
         rd = early_rd;
         early_rd = NULL;
@@ -172,23 +334,48 @@ int run_tally(const pssbam_config *cfg, Genome *genome, const char *aln_path, in
     }
     if (!rd && !sd) {
         fprintf(stderr, "Error: Unable to open %s: %s\n", aln_path, err);
-        return -1;
+        goto done;
     }
     t_open = now_s() - t_mark; t_mark = now_s();
-    for (int g = 0; g < n_gpus; g++) {
-        pssbam_config c = *cfg;
-        const int have = pssbam_device_count();
-        c.device = have > 0 ? g % have : g;
-        if (pssbam_engine_create(&c, &eng[g]) || pssbam_engine_set_genome(eng[g], genome)) {
-            fprintf(stderr, "Error: GPU engine %d: %s\n", g, pssbam_last_error());
+    if (adopted) {
+        /* the helper created the engines, fed the file and (usually) set the genome when it was posted */
+        if (EF.feed_rc || EF.failed) {
+            if (EF.err[0]) fprintf(stderr, "Error: %s\n", EF.err);
             goto done;
         }
+        if (!EF.genome_set) { /* the feed ended before it looked at the gate (a file it does not take) */
+            const bam_header *h = bam_reader_header(rd);
+            for (int g = 0; g < n_gpus; g++)
+                if (pssbam_engine_set_genome(eng[g], genome) || pssbam_engine_set_references(eng[g], h->n_ref, (const char *const *)h->ref_name)) {
+                    fprintf(stderr, "Error: GPU engine %d: %s\n", g, pssbam_last_error());
+                    goto done;
+                }
+        }
+        refs_sent = bam_reader_header(rd)->n_ref;
+        dfs = EF.dfs;
+        if (verbose)
+            fprintf(stderr, "[pssbam] early feed (helper thread, seconds after start-up began): HIP runtime up %.3f, engines %.3f, genome posted %.3f, "
+                            "genome + references on the engines %.3f (took %.3f), feed drained %.3f\n", EF.t_hip, EF.t_engines, EF.t_posted,
+                    EF.t_genome_set, EF.t_genome_set_dur, EF.t_feed_end);
+    } else {
+        for (int g = 0; g < n_gpus; g++) {
+            pssbam_config c = *cfg;
+            const int have = pssbam_device_count();
+            c.device = have > 0 ? g % have : g;
+            if (pssbam_engine_create(&c, &eng[g])) {
+                fprintf(stderr, "Error: GPU engine %d: %s\n", g, pssbam_last_error());
+                goto done;
+            }
+        }
+        /* every GPU's upload is enqueued before the first one is waited for */
+        for (int g = 0; g < n_gpus; g++)
+            if (pssbam_engine_set_genome_async(eng[g], genome)) {
+                fprintf(stderr, "Error: GPU engine %d: %s\n", g, pssbam_last_error());
+                goto done;
+            }
     }
     t_engine = now_s() - t_mark; t_mark = now_s();
-    device_feed_stats dfs;
-    memset(&dfs, 0, sizeof dfs);
-    int fed_on_device = 0;
-    if (device_feed && rd) {
+    if (device_feed && rd && !adopted) {
         const bam_header *h = bam_reader_header(rd);
         for (int g = 0; g < n_gpus; g++)
             if (pssbam_engine_set_references(eng[g], h->n_ref, (const char *const *)h->ref_name)) {
@@ -206,7 +393,9 @@ int run_tally(const pssbam_config *cfg, Genome *genome, const char *aln_path, in
                 for (int g = 0; g < n_gpus; g++) (void)pssbam_engine_hint_records(eng[g], r0, nb0);
             if (slot0 >= 0) bam_reader_release(rd, slot0);
         }
-        if (run_device_feed(eng, n_gpus, aln_path, bam_reader_header_bytes(rd), feed_run(n_gpus), verbose, &dfs)) goto done;
+        if (run_device_feed(eng, n_gpus, aln_path, bam_reader_header_bytes(rd), feed_run(n_gpus), verbose, &dfs, NULL)) goto done;
+    }
+    if (device_feed && rd) {
         if (dfs.fallback) {
             if (verbose) fprintf(stderr, "[pssbam] device feed not usable for this file: falling back to the host reader\n");
             for (int g = 0; g < n_gpus; g++)

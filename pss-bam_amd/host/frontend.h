@@ -26,15 +26,18 @@ int run_tally(const pssbam_config *cfg, Genome *genome, const char *aln_path, in
  * unless $PSSBAM_CLEAN_EXIT is), run_tally() leaves engines, pinned slots and the mapped input
  * to process exit instead of releasing ~4 GB piece by piece (0.12 s of a 0.7 s command), and
  * front_end_exit() ends the process without running destructors. */
-/* Start-up work that overlaps the caller's FASTA load (returns at once): opens the BAM reader
- * early if aln_path is a BGZF BAM -- it starts inflating its first batches immediately -- and, on a
- * helper thread, brings up the HIP runtime + device contexts and page-locks the reader's slots.
- * run_tally() picks all of it up.  aln_path may be NULL. */
-void frontend_warmup_start(const char *aln_path);
+/* Start-up work that overlaps the caller's FASTA load (returns at once).  If aln_path is a BGZF BAM the
+ * device feed takes, a helper thread brings the HIP runtime up, creates the engines from `cfg` and feeds the
+ * compressed file to them right away -- inflate, CRC-32 and record index need no genome; run_tally() (same
+ * cfg, same path) posts the Genome when the caller has it and collects the result.  Otherwise (SAM text, host
+ * inflate, cfg == NULL) the helper only warms the runtime up and page-locks the host reader's slots.
+ * fasta_path (may be NULL) only sizes the device memory left alone for the genome.  aln_path may be NULL. */
+void frontend_warmup_start(const pssbam_config *cfg, const char *aln_path, const char *fasta_path);
 
 extern int frontend_fast_exit;
 void front_end_exit(int status);
 void run_result_free(run_result *res);
 double frontend_now_s(void); /* CLOCK_MONOTONIC seconds */
+double frontend_process_age_s(void); /* seconds since the process was created (10 ms resolution), -1 if unknown */
 int env_gpu_count(void); /* PSSBAM_NGPU, default 1, clamped to the devices present */
 #endif

@@ -23,7 +23,7 @@
 
 int main(int argc, char *argv[])
 {
-    const double t_main = frontend_now_s();
+    const double t_main = frontend_now_s(), age_main = frontend_process_age_s();
     int region_len = 15, min_mq = 0, merged_only = 0, option;
     unsigned long min_read_len = 0, max_read_len = 250000000;
     const char *up_ctx = "ACGT", *down_ctx = "ACGT";
@@ -84,17 +84,6 @@ int main(int argc, char *argv[])
     if (read_group) fprintf(stderr, " -R %s", read_group);
     fprintf(stderr, " -U %s -D %s%s\n", up_ctx, down_ctx, merged_only ? " -m" : "");
 
-    fprintf(stderr, "Reading genome sequence from:\n%s\n", fasta_fn);
-    frontend_warmup_start(bam_fn);   /* HIP start-up overlaps the FASTA load */
-    const double t_fa = frontend_now_s();
-    Genome *genome = init_genome(fasta_fn);
-    if (getenv("PSSBAM_STATS")) fprintf(stderr, "[pssbam] genome: fasta load %.3f s\n", frontend_now_s() - t_fa);
-    if (!genome) {
-        fprintf(stderr, "Error: Unable to load genome from %s.\n", fasta_fn);
-        exit(1);
-    }
-    fprintf(stderr, "Finished loading genome.\nCounting matches/mismatches from:\n%s\n", bam_fn);
-
     pssbam_config cfg;
     memset(&cfg, 0, sizeof cfg);
     cfg.abi_version = PSSBAM_ABI_VERSION;
@@ -109,6 +98,19 @@ int main(int argc, char *argv[])
     cfg.read_group = read_group;
     cfg.device = 0;
     cfg.kernel = PSSBAM_KERNEL_AUTO;
+
+    fprintf(stderr, "Reading genome sequence from:\n%s\n", fasta_fn);
+    /* HIP start-up, engines and the compressed BAM feed (PCIe, inflate, CRC, record index) overlap the FASTA
+     * load; only the tally launches wait for the genome (frontend.c) */
+    frontend_warmup_start(&cfg, bam_fn, fasta_fn);
+    const double t_fa = frontend_now_s();
+    Genome *genome = init_genome(fasta_fn);
+    if (getenv("PSSBAM_STATS")) fprintf(stderr, "[pssbam] genome: fasta load %.3f s\n", frontend_now_s() - t_fa);
+    if (!genome) {
+        fprintf(stderr, "Error: Unable to load genome from %s.\n", fasta_fn);
+        exit(1);
+    }
+    fprintf(stderr, "Finished loading genome.\nCounting matches/mismatches from:\n%s\n", bam_fn);
 
     run_result res;
     frontend_fast_exit = getenv("PSSBAM_CLEAN_EXIT") == NULL;
@@ -129,6 +131,8 @@ int main(int argc, char *argv[])
                     ? "  (more than 1 % of the records were longer than the staged prefix and took the one-lane path: slower, same tables)" : "");
         fprintf(stderr, "[pssbam] gpus=%d inflate_s=%.3f total_s=%.3f\n", res.n_gpus, res.inflate_s, res.total_s);
         fprintf(stderr, "[pssbam] main() to reports written: %.3f s\n", frontend_now_s() - t_main);
+        fprintf(stderr, "[pssbam] process creation to main(): %.2f s (exec + dynamic loading); process creation to reports written: %.2f s\n", age_main,
+                frontend_process_age_s());
     }
     if (frontend_fast_exit) { /* nothing left to do but to hand the memory back: let the OS */
         fprintf(stderr, "Done.\n");

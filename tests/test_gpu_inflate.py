@@ -343,6 +343,14 @@ def test_cli_device_feed_and_fallback(pkg, oracle, tmp_path):
     err = run_pss(aligned, {})
     m = re.search(r"device feed: (\d+) submits", err)
     assert m and "host reader" not in err, err[-1500:]
+    # by default the feed runs on a helper thread WHILE the FASTA loads (tallies put off until the genome is
+    # posted); PSSBAM_NO_EARLY_FEED keeps the serial order of the reference -- same tables either way
+    assert "early feed (helper thread" in err, err[-1500:]
+    err = run_pss(aligned, {"PSSBAM_NO_EARLY_FEED": "1"})
+    assert "early feed (helper thread" not in err and re.search(r"device feed: (\d+) submits", err)
+    err = run_pss(aligned, {"PSSBAM_FEED_MAX_SLOTS": "1", "PSSBAM_FEED_SUPER_BYTES": str(2 << 20), "PSSBAM_FEED_BATCH_BYTES": str(1 << 20),
+                            "PSSBAM_CHUNK_BYTES": str(1 << 20)})       # the ring fills before the genome comes: the feed waits for it
+    assert "early feed (helper thread" in err
     err = run_pss(aligned, {"PSSBAM_CHUNK_BYTES": str(1 << 20), "PSSBAM_FEED_BATCH_BYTES": str(3 << 20), "PSSBAM_NGPU": "2",
                             "PSSBAM_OVERSUBSCRIBE": "1", "PSSBAM_LOADER_THREADS": "3", "PSSBAM_RUN_BATCHES": "2"})
     m = re.search(r"device feed: (\d+) submits", err)
@@ -439,3 +447,143 @@ def test_cli_damaged_record_stream_same_outcome_in_both_feeds(pkg, tmp_path):
         assert (res[0] == 0) == (res[1] == 0), (f, res)
         if res[0] == 0:
             assert (tmp_path / "d.pss.counts.txt").read_text().split("\n", 6)[-1] == (tmp_path / "h.pss.counts.txt").read_text().split("\n", 6)[-1], f
+
+
+def test_feed_ahead_of_the_genome(pkg, tmp_path, monkeypatch):
+    """pssbam_engine_feed_open: the compressed file goes in BEFORE set_genome / set_references -- inflate, CRC and
+    record index run at once, the tally launches follow when the genome arrives.  Same tables as the serial order;
+    with a ring that may not grow (PSSBAM_FEED_MAX_SLOTS) the engine answers PSSBAM_EBUSY, takes nothing of the
+    chunk, and carries on once the genome is set."""
+    contigs, refs, recs = tl.fuzz_dataset(515, 6000, with_rg=True)
+    bam = tmp_path / "a.bam"
+    tl.write_bam(bam, refs, recs, level=6, rng=np.random.default_rng(8), block=4000)    # records cross blocks
+    raw = np.frombuffer(bam.read_bytes(), dtype=np.uint8)
+    hb = _bam_header_bytes(bam.read_bytes())
+    pss, kmer = dict(region_len=20, min_mq=5), dict(klen=3)
+    eng = pkg.Engine(pss=pss, kmer=kmer, read_group="grpB")
+    eng.set_genome_arrays(tl.loaded_contigs(contigs))
+    eng.set_references([n for n, _ in refs])
+    eng.submit(tl.raw_records(refs, recs))
+    want = eng.finish()
+    eng.close()
+    monkeypatch.setenv("PSSBAM_FEED_SUPER_BYTES", str(1 << 20))      # ~25 super-batches
+    for max_slots, batch in ((None, 1 << 30), ("2", 60000), ("1", 50000), ("40", 200000)):   # (ONE submit is never cut short: it may pass the cap)
+        if max_slots:
+            monkeypatch.setenv("PSSBAM_FEED_MAX_SLOTS", max_slots)
+        else:
+            monkeypatch.delenv("PSSBAM_FEED_MAX_SLOTS", raising=False)
+        eng = pkg.Engine(pss=pss, kmer=kmer, read_group="grpB")
+        with pytest.raises(pkg.PssbamError):                          # neither genome nor feed_open: refused
+            eng.submit_bgzf(raw, header_bytes=hb)
+        eng.feed_open(len(refs))
+        busy = []
+
+        def set_genome():
+            busy.append(1)
+            eng.set_genome_arrays(tl.loaded_contigs(contigs))
+            eng.set_references([n for n, _ in refs])
+        eng.submit_bgzf(raw, header_bytes=hb, max_batch_inflated=batch, on_busy=set_genome)
+        ebusy = bool(busy)
+        assert ebusy == (max_slots in ("1", "2")), (max_slots, busy)  # a ring that may not grow fills up; one that may does not
+        if not ebusy:
+            with pytest.raises(pkg.PssbamError):                      # fed, but the genome never came
+                eng.sync()
+            set_genome()
+        st = eng.feed_status()
+        got = eng.finish()
+        eng.close()
+        assert st["flags"] == 0, (max_slots, st)
+        assert np.array_equal(got.fwd, want.fwd) and np.array_equal(got.rev, want.rev), max_slots
+        assert np.array_equal(got.k5, want.k5) and np.array_equal(got.k3, want.k3), max_slots
+        a, b = dict(got.stats), dict(want.stats)
+        a.pop("slow_path"), b.pop("slow_path")
+        assert a == b, (max_slots, a, b)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_submit_bgzf_matches_the_oracle(pkg, oracle, tmp_path, seed):
+    """the compressed feed against the ORACLE (not against the engine's own host path): random records incl. aux
+    fields of every type, random options, both BGZF layouts, with and without -R"""
+    with_rg = seed % 2 == 1
+    contigs, refs, recs = tl.fuzz_dataset(8800 + seed, 3000, with_rg=with_rg, extras=True)
+    fa = tmp_path / "g.fa"
+    tl.write_fasta(fa, contigs)
+    bam = tmp_path / "a.bam"
+    if seed < 2:
+        hb = tl.write_bam_aligned(bam, refs, recs, level=1 + seed * 5, rng=np.random.default_rng(seed))
+    else:
+        tl.write_bam(bam, refs, recs, level=6, rng=np.random.default_rng(seed), block=[900, 30000][seed - 2])
+        hb = _bam_header_bytes(bam.read_bytes())
+    raw = np.frombuffer(bam.read_bytes(), dtype=np.uint8)
+    g = oracle.load_genome(fa)
+    rng = np.random.default_rng(100 + seed)
+    try:
+        for trial in range(3):
+            po, ko = tl.random_pss_opts(rng), tl.random_fk_opts(rng)
+            rg = [None, "grpA", "grpB"][trial] if with_rg else None
+            keep = recs if rg is None else [r for r in recs if ("RG", "Z", rg) in r.tags]
+            sam = tmp_path / f"t{trial}.sam"
+            tl.write_sam(sam, refs, keep)
+            wf, wr, st = oracle.pss(g, sam, po)
+            w5, w3, stk = oracle.fragkon(g, sam, ko)
+            eng = pkg.Engine(pss=dict(region_len=po.region_len, min_read_len=po.min_read_len, max_read_len=po.max_read_len,
+                                      min_mq=po.min_mq, up_ctx=po.up_ctx, down_ctx=po.down_ctx, merged_only=po.merged_only),
+                             kmer=dict(klen=ko.klen, min_mq=ko.min_mq, min_read_len=ko.min_read_len, max_read_len=ko.max_read_len,
+                                       merged_only=ko.merged_only), read_group=rg)
+            if trial == 1:
+                eng.feed_open(len(refs))                 # ahead of the genome
+                eng.submit_bgzf(raw, header_bytes=hb, max_batch_inflated=300000)
+            eng.set_genome_arrays(tl.loaded_contigs(contigs))
+            eng.set_references([n for n, _ in refs])
+            if trial != 1:
+                eng.submit_bgzf(raw, header_bytes=hb, max_batch_inflated=[1 << 30, 0, 90000][trial])
+            assert eng.feed_status()["flags"] == 0
+            got = eng.finish()
+            eng.close()
+            assert np.array_equal(got.fwd, wf) and np.array_equal(got.rev, wr), (seed, trial, po)
+            assert np.array_equal(got.k5, w5.astype(np.uint64)) and np.array_equal(got.k3, w3.astype(np.uint64)), (seed, trial, ko)
+            assert got.stats["records"] == len(recs) and got.stats["rg_dropped"] == len(recs) - len(keep)
+            assert got.stats["pss_ok"] == st[tl.ST_OK] and got.stats["pss_filtered"] == st[tl.ST_FILTERED]
+            assert got.stats["no_contig"] == st[tl.ST_NO_CONTIG] and got.stats["parse_skip"] == st[tl.ST_PARSE_SKIP]
+            assert got.stats["kmer_ok"] == stk[tl.ST_OK] and got.stats["kmer_fail"] == stk[tl.ST_KMER_FAIL]
+    finally:
+        oracle.free_genome(g)
+
+
+def test_empty_block_behind_the_header_and_a_bad_first_record(pkg, tmp_path):
+    """an empty BGZF block right behind the header block leaves block 0 of the feed without a record: the chain's
+    anchor must still be checked against the first candidate a later block finds.  With a first record whose refID
+    equals n_ref (implausible) the device feed may not drop it silently: same outcome as the host reader"""
+    import os
+    import subprocess
+    contigs, refs, recs = tl.fuzz_dataset(4321, 1200)
+    fa = tmp_path / "g.fa"
+    tl.write_fasta(fa, contigs)
+    idx = {n: i for i, (n, _) in enumerate(refs)}
+    head = tl.bam_bytes(refs, [])
+    body = [tl.bam_record(r, idx) for r in recs]
+    bad_first = bytearray(body[0])
+    bad_first[4:8] = struct.pack("<i", len(refs))                    # refID == n_ref
+    b = pkg.PKG_DIR / "bin" / "pss-bam"
+    outcomes = {}
+    for name, first in (("good", body[0]), ("bad", bytes(bad_first))):
+        data = first + b"".join(body[1:])
+        bam = tmp_path / f"{name}.bam"
+        bam.write_bytes(tl.bgzf_block(head, 6) + tl.bgzf_block(b"", 6)
+                        + b"".join(tl.bgzf_block(data[i:i + 0xFF00], 6) for i in range(0, len(data), 0xFF00)) + tl.BGZF_EOF)
+        res = []
+        for tag, env in (("d", {}), ("h", {"PSSBAM_DEVICE_INFLATE": "0"})):
+            pr = subprocess.run([str(b), "-F", str(fa), "-B", str(bam), "-o", str(tmp_path / (name + tag)), "-r", "10"],
+                                capture_output=True, text=True, env={**os.environ, "PSSBAM_STATS": "1", **env}, timeout=120)
+            assert pr.returncode >= 0, (name, tag, pr.stderr[-500:])
+            res.append((pr.returncode == 0, (tmp_path / f"{name}{tag}.pss.counts.txt").read_text().split("\n", 6)[-1] if pr.returncode == 0 else None,
+                        re_records(pr.stderr)))
+        assert res[0] == res[1], (name, res[0][0], res[1][0], res[0][2], res[1][2])
+        outcomes[name] = res[0]
+    assert outcomes["good"][0] and outcomes["good"][2] == len(recs)
+
+
+def re_records(stderr: str):
+    import re
+    m = re.search(r"\[pssbam\] records=(\d+)", stderr)
+    return int(m.group(1)) if m else None

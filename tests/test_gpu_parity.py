@@ -327,3 +327,65 @@ def test_prefix_sample_covers_late_long_records(pkg, oracle, tmp_path):
             hip.hipFree(d_r), hip.hipFree(d_o)
         _check_pss(got, wf, wr, st)
         assert got.stats["slow_path"] == 0, (mode, got.stats)
+
+
+@pytest.mark.parametrize("region_len", [16, 17])
+def test_compact_tiled_switch_at_sixteen(pkg, oracle, tmp_path, monkeypatch, region_len):
+    """-r 16 is tally_compact's last position column (slot 15 of the half tables, second v_perm group), -r 17 the
+    first tally_tiled case: both pinned against the oracle, with and without -R, and PSSBAM_COMPACT=0 as the
+    cross-check of the switch itself (csrc/engine.hip: rows <= COMPACT_MAX_ROWS)"""
+    contigs, refs, recs = tl.fuzz_dataset(1600 + region_len, 3000, with_rg=True)
+    fa = tmp_path / "g.fa"
+    tl.write_fasta(fa, contigs)
+    raw = tl.raw_records(refs, recs)
+    g = oracle.load_genome(fa)
+    try:
+        for rg in (None, "grpA"):
+            keep = recs if rg is None else [r for r in recs if ("RG", "Z", rg) in r.tags]
+            sam = tmp_path / f"{rg}.sam"
+            tl.write_sam(sam, refs, keep)
+            for po in (tl.PssOpts(region_len=region_len), tl.PssOpts(region_len=region_len, min_mq=20, up_ctx="CT", down_ctx="ACGTN")):
+                wf, wr, st = oracle.pss(g, sam, po)
+                for compact in ("1", "0"):
+                    monkeypatch.setenv("PSSBAM_COMPACT", compact)
+                    for kern in (pkg.KERNEL_SIMPLE, pkg.KERNEL_TILED):
+                        got = _engine_tables(pkg, contigs, refs, raw, pss=_pss_dict(po), rg=rg, kernel=kern, chunks=2)
+                        _check_pss(got, wf, wr, st)
+    finally:
+        oracle.free_genome(g)
+
+
+def test_read_group_behind_large_aux_arrays(pkg, oracle, tmp_path):
+    """B arrays of thousands of elements (every sub-type), H strings and floats in front of and behind RG:Z: the -R
+    walk of the device decoders must step over all of them by type (reference: `samtools view -r`,
+    pss-bam.c:150-155).  BAM only -- text of this size would overflow the reference's 2047-byte tag buffer
+    (precondition P2), and the oracle never looks at tags: it gets the kept records without them"""
+    contigs, refs, recs = tl.fuzz_dataset(2718, 1500, with_rg=True)
+    rng = np.random.default_rng(5)
+    subs = "cCsSiIf"
+    for i, r in enumerate(recs):
+        sub = subs[i % 7]
+        n = [0, 1, 700, 5000][(i // 7) % 4]
+        lo, hi = tl._B_RANGE.get(sub, (0, 1))
+        vals = [float(np.float32(x)) for x in rng.normal(0, 9, n)] if sub == "f" else [int(x) for x in rng.integers(lo, hi, n)]
+        big = ("ZB", "B", (sub, vals))
+        r.tags.insert(0 if i % 2 else len(r.tags), big)
+        if i % 5 == 0:
+            r.tags.insert(0, ("XH", "H", "AB" * int(rng.integers(0, 400))))
+    fa = tmp_path / "g.fa"
+    tl.write_fasta(fa, contigs)
+    raw = tl.raw_records(refs, recs)
+    g = oracle.load_genome(fa)
+    try:
+        for rg in ("grpA", "grpB"):
+            keep = [tl.Rec(**{**r.__dict__, "tags": []}) for r in recs if ("RG", "Z", rg) in r.tags]
+            sam = tmp_path / f"{rg}.sam"
+            tl.write_sam(sam, refs, keep)
+            po = tl.PssOpts(region_len=20)
+            wf, wr, st = oracle.pss(g, sam, po)
+            for kern in (pkg.KERNEL_SIMPLE, pkg.KERNEL_TILED):
+                got = _engine_tables(pkg, contigs, refs, raw, pss=_pss_dict(po), rg=rg, kernel=kern)
+                _check_pss(got, wf, wr, st)
+                assert got.stats["rg_dropped"] == len(recs) - len(keep)
+    finally:
+        oracle.free_genome(g)

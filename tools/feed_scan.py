@@ -74,7 +74,10 @@ for st in settings:
                       "device_feed": feed.group(1) if feed else None, "feed_thread": thr.group(1) if thr else None,
                       "phases": ph.group(1) if ph else None,
                       "engine_feed": ef.group(1) if ef else None, "main_to_reports_s": float(mn.group(1)) if mn else None,
-                      "fasta_load_s": float(fl.group(1)) if fl else None}), flush=True)
+                      "fasta_load_s": float(fl.group(1)) if fl else None,
+                      "early_feed": (lambda m_: m_.group(1) if m_ else None)(re.search(r"early feed \(helper thread[^:]*\): (.*)\n", best[1])),
+                      "process": (lambda m_: m_.group(1) if m_ else None)(re.search(r"process creation to main\(\): (.*)\n", best[1])),
+                      "device": (lambda m_: m_.group(1) if m_ else None)(re.search(r"\[pssbam\] device: (.*)\n", best[1]))}), flush=True)
 for p in tmp.iterdir():
     p.unlink()
 tmp.rmdir()
