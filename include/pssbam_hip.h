@@ -127,7 +127,10 @@ int pssbam_engine_set_genome(pssbam_engine *e, const struct genome *g);
  * run on a stream of their own; tally launches wait for them on the device), so one host thread can start
  * the uploads of several GPUs at once and the engine's stream keeps inflating meanwhile.  The Genome must
  * stay untouched until pssbam_engine_genome_wait, _sync or _finish has returned.  The reference loads the
- * genome, then loops (pss-bam.c:751-783); this is what lets the replacement overlap the two. */
+ * genome, then loops (pss-bam.c:751-783); this is what lets the replacement overlap the two.
+ * The one exception to "one thread per engine": after pssbam_engine_feed_open, set_genome_async may be called
+ * from ANOTHER thread while the owning thread keeps submitting compressed blocks, provided set_references
+ * follows on the owning thread after set_genome_async has returned. */
 int pssbam_engine_set_genome_async(pssbam_engine *e, const struct genome *g);
 int pssbam_engine_genome_wait(pssbam_engine *e);
 

@@ -233,65 +233,89 @@ static constexpr uint64_t FEED_SUB_MAX = (3584ull << 20);   // records per tally
 // to a second depending on what the driver has to reclaim.  What no engine took goes back with
 // pssbam_feed_release.
 namespace {
-struct FeedReserve { uint8_t *comp[2] = {nullptr, nullptr}, *out[2] = {nullptr, nullptr}; size_t comp_cap = 0, out_cap = 0; };
+struct FeedReserve {
+    uint8_t *comp[FEED_SLOTS_READY] = {nullptr}, *out[FEED_SLOTS_READY] = {nullptr};
+    size_t comp_cap = 0, out_cap = 0;
+    int pending = 0;   // pairs a pssbam_feed_reserve call in progress has yet to publish
+};
 FeedReserve g_feed_reserve[64];
 std::mutex g_feed_reserve_mu;
+std::condition_variable g_feed_reserve_cv;
 }  // namespace
 
+// Allocates the buffers of the feed's first slots for `device` and publishes them one by one (an engine that needs a
+// slot meanwhile waits for the next one instead of allocating beside this thread: device allocations of this size take
+// from a millisecond to hundreds of ms each, depending on what the driver has to clear -- profiles/r03_exit_teardown.txt).
 extern "C" int pssbam_feed_reserve(int device) {
     if (device < 0 || device >= 64) return fail(PSSBAM_EINVAL, "device %d out of range", device);
-    HIP_TRY(hipSetDevice(device));
-    FeedReserve r;
-    r.comp_cap = (size_t)FEED_COMP_CAP;
-    r.out_cap = (size_t)(FEED_GAP + FEED_OUT_TARGET + FEED_OUT_SLACK);
-    for (int k = 0; k < 2; k++) {
-        HIP_TRY(hipMalloc(&r.comp[k], r.comp_cap + 64));
-        HIP_TRY(hipMalloc(&r.out[k], r.out_cap));
+    {
+        std::lock_guard<std::mutex> lk(g_feed_reserve_mu);
+        FeedReserve &r = g_feed_reserve[device];
+        if (r.pending) return PSSBAM_OK;   // somebody is at it
+        for (int k = 0; k < FEED_SLOTS_READY; k++)
+            if (r.comp[k]) return PSSBAM_OK;   // ... or has been
+        r.comp_cap = (size_t)FEED_COMP_CAP;
+        r.out_cap = (size_t)(FEED_GAP + FEED_OUT_TARGET + FEED_OUT_SLACK);
+        r.pending = FEED_SLOTS_READY;
     }
-    std::lock_guard<std::mutex> lk(g_feed_reserve_mu);
-    if (g_feed_reserve[device].comp[0] || g_feed_reserve[device].comp[1]) {   // somebody was faster: keep theirs
-        for (int k = 0; k < 2; k++) { (void)hipFree(r.comp[k]); (void)hipFree(r.out[k]); }
-        return PSSBAM_OK;
+    int rc = PSSBAM_OK;
+    hipError_t err = hipSetDevice(device);
+    for (int k = 0; k < FEED_SLOTS_READY; k++) {
+        uint8_t *c = nullptr, *o = nullptr;
+        if (err == hipSuccess) err = hipMalloc(&c, (size_t)FEED_COMP_CAP + 64);
+        if (err == hipSuccess) err = hipMalloc(&o, (size_t)(FEED_GAP + FEED_OUT_TARGET + FEED_OUT_SLACK));
+        std::lock_guard<std::mutex> lk(g_feed_reserve_mu);
+        FeedReserve &r = g_feed_reserve[device];
+        if (err == hipSuccess) { r.comp[k] = c; r.out[k] = o; }
+        else if (c) (void)hipFree(c);
+        r.pending--;
+        g_feed_reserve_cv.notify_all();
     }
-    g_feed_reserve[device] = r;
-    return PSSBAM_OK;
+    if (err != hipSuccess) rc = fail(PSSBAM_EHIP, "reserving feed buffers failed: %s", hipGetErrorString(err));
+    return rc;
 }
 
 extern "C" int pssbam_feed_release(int device) {
     if (device < 0 || device >= 64) return fail(PSSBAM_EINVAL, "device %d out of range", device);
     FeedReserve r;
     {
-        std::lock_guard<std::mutex> lk(g_feed_reserve_mu);
+        std::unique_lock<std::mutex> lk(g_feed_reserve_mu);
+        g_feed_reserve_cv.wait(lk, [&] { return g_feed_reserve[device].pending == 0; });
         r = g_feed_reserve[device];
         g_feed_reserve[device] = FeedReserve();
     }
-    if (!r.comp[0] && !r.comp[1]) return PSSBAM_OK;
+    bool any = false;
+    for (int k = 0; k < FEED_SLOTS_READY; k++) any = any || r.comp[k];
+    if (!any) return PSSBAM_OK;
     HIP_TRY(hipSetDevice(device));
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < FEED_SLOTS_READY; k++) {
         if (r.comp[k]) (void)hipFree(r.comp[k]);
         if (r.out[k]) (void)hipFree(r.out[k]);
     }
     return PSSBAM_OK;
 }
 
-// takes one (comp, out) pair from the device's reserve, if there is one of the wanted size
+// takes one (comp, out) pair from the device's reserve, if there is (or is about to be) one of the wanted size
 static bool feed_take_reserved(int device, size_t comp_cap, size_t out_need, uint8_t **comp, uint8_t **out, size_t *out_cap) {
     if (device < 0 || device >= 64) return false;
-    std::lock_guard<std::mutex> lk(g_feed_reserve_mu);
+    std::unique_lock<std::mutex> lk(g_feed_reserve_mu);
     FeedReserve &r = g_feed_reserve[device];
-    if (r.comp_cap != comp_cap || r.out_cap < out_need) return false;
-    for (int k = 0; k < 2; k++)
-        if (r.comp[k]) {
-            *comp = r.comp[k];
-            *out = r.out[k];
-            *out_cap = r.out_cap;
-            r.comp[k] = r.out[k] = nullptr;
-            return true;
-        }
-    return false;
+    for (;;) {
+        if (r.comp_cap != comp_cap || r.out_cap < out_need) return false;
+        for (int k = 0; k < FEED_SLOTS_READY; k++)
+            if (r.comp[k]) {
+                *comp = r.comp[k];
+                *out = r.out[k];
+                *out_cap = r.out_cap;
+                r.comp[k] = r.out[k] = nullptr;
+                return true;
+            }
+        if (!r.pending) return false;
+        g_feed_reserve_cv.wait(lk);
+    }
 }
 
-static bool feed_engine_ready(const pssbam_engine *e) { return e->d_genome && e->have_refs; }
+static bool feed_engine_ready(const pssbam_engine *e) { return e->have_refs; }   // (set_references needs the genome: implied)
 
 // what one slot of the ring costs in device memory (buffers + offset index), for the budget
 static uint64_t feed_slot_bytes(const pssbam_engine *e) {
@@ -337,6 +361,7 @@ static int feed_acquire(pssbam_engine *e, int *out_slot, bool force) {
     }
     (void)hipGetLastError();   // (hipErrorNotReady is not an error)
     size_t limit = FEED_SLOTS_READY;
+    if (const char *v = getenv("PSSBAM_FEED_SLOTS")) limit = std::max<size_t>(2, (size_t)atoi(v));   // (experiments: the ring's depth once the genome is set)
     if (!feed_engine_ready(e)) {
         if (!e->feed_mem_budget) {
             size_t free_b = 0, total_b = 0;

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -487,7 +488,7 @@ static int genome_upload(pssbam_engine *e, size_t n, const char *const *ids, con
     e->contig_ids.clear();
     for (size_t k = 0; k < n; k++) e->contig_ids.emplace_back(ids[order[k]]);
     e->star_contig = -1;
-    e->have_refs = false;
+    if (e->have_refs) e->have_refs = false;   // (written only when it changes: another thread may be feeding, see pssbam_hip.h)
     {   // RNAME "*" (refID -1) goes through find_seq like any other name
         auto it = std::lower_bound(e->contig_ids.begin(), e->contig_ids.end(), std::string("*"),
                                    [](const std::string &a, const std::string &b) { return strcmp(a.c_str(), b.c_str()) < 0; });

@@ -226,6 +226,9 @@ static void loader_pin(feed_loader *F)
 
 /* ---- start-up overlap: the front end opens the loader while the FASTA is still being parsed ---- */
 static feed_loader *g_pre = NULL;
+/* a loader whose feed has ended: its threads are done, but un-pinning and freeing 300+ MB of staging slots costs tens of
+ * ms -- the caller's tables are ready without that (device_feed_prefetch_cancel does it, or process exit) */
+static feed_loader *g_retired = NULL;
 
 void device_feed_prefetch(const char *path)
 {
@@ -241,6 +244,8 @@ void device_feed_prefetch_cancel(void)
 {
     loader_close(g_pre);
     g_pre = NULL;
+    loader_close(g_retired);
+    g_retired = NULL;
 }
 
 int run_device_feed(pssbam_engine *const *eng, int n_gpus, const char *path, size_t header_bytes, int run, int verbose,
@@ -458,7 +463,8 @@ done:
         pthread_mutex_unlock(&L->mu);
         for (int g = 0; g < n_gpus; g++) (void)pssbam_engine_sync(eng[g]);
     }
-    loader_close(F);
+    if (rc == 0 && !g_retired) g_retired = F;   /* (nothing reads the slots any more: every copy was waited for) */
+    else loader_close(F);
     free(blocks);
     free(grp);
     return rc;

@@ -18,6 +18,7 @@
 
 int main(int argc, char *argv[])
 {
+    frontend_detach_start();   /* (frontend.c: the caller does not wait for the teardown) */
     int klen = 8, min_mq = 0, merged_only = 0, option;
     unsigned long min_read_len = 0, max_read_len = 250000000;
     char *fasta_fn = NULL, *bam_fn = NULL;

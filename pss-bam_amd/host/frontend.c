@@ -8,12 +8,17 @@
  */
 #include "frontend.h"
 
+#include <errno.h>
+#include <fcntl.h>
 #include <pthread.h>
+#include <signal.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <sys/stat.h>
+#include <sys/types.h>
+#include <sys/wait.h>
 #include <time.h>
 #include <unistd.h>
 
@@ -42,52 +47,69 @@ static struct early_feed {
     char *up, *down, *rg;           /* the strings cfg points at */
     uint64_t fasta_bytes;
     pssbam_engine *eng[64];
-    int n_gpus, engines_ok, fed, feed_rc, genome_set, failed;
+    int n_gpus, engines_ok, engines_done, fed, feed_rc, genome_set, failed;
     device_feed_stats dfs;
     char err[600];
     pthread_mutex_t mu;
     pthread_cond_t cv;
-    Genome *genome;
-    int posted, abandon;
-    double t0, t_hip, t_engines, t_posted, t_genome_set, t_genome_set_dur, t_feed_end;
+    int posted, abandon;            /* posted: the genome upload is enqueued on every engine (by run_tally's thread) */
+    double t0, t_hip, t_engines, t_posted, t_upload_dur, t_genome_set, t_genome_set_dur, t_feed_end;
 } EF = {.mu = PTHREAD_MUTEX_INITIALIZER, .cv = PTHREAD_COND_INITIALIZER};
 
-/* device_feed.h feed_gate: 1 = genome and references are on every engine */
+/* device_feed.h feed_gate: 1 = genome and references are on every engine.  The upload itself (page-locking the
+ * contigs, 3 GB of copies per GPU) is enqueued by run_tally's thread -- 60 ms of host work the feeding thread does
+ * not have: its super-batches keep going out meanwhile; here only the reference table follows (a few KB), after
+ * which the engine tallies what it inflated ahead. */
 static int early_gate(void *ctx, int block)
 {
     (void)ctx;
     pthread_mutex_lock(&EF.mu);
     while (!EF.posted && !EF.abandon && block) pthread_cond_wait(&EF.cv, &EF.mu);
     const int abandon = EF.abandon, posted = EF.posted;
-    Genome *genome = EF.genome;
     pthread_mutex_unlock(&EF.mu);
     if (abandon) return -1;
     if (!posted) return 0;
     if (!EF.genome_set) {
         const double t = frontend_now_s();
         const bam_header *h = bam_reader_header(early_rd);
-        /* every GPU's upload is enqueued before the first one is waited for: the links run side by side */
         for (int g = 0; g < EF.n_gpus; g++)
-            if (pssbam_engine_set_genome_async(EF.eng[g], genome)) goto fail;
-        for (int g = 0; g < EF.n_gpus; g++)
-            if (pssbam_engine_set_references(EF.eng[g], h->n_ref, (const char *const *)h->ref_name)) goto fail;
+            if (pssbam_engine_set_references(EF.eng[g], h->n_ref, (const char *const *)h->ref_name)) {
+                snprintf(EF.err, sizeof EF.err, "GPU engine: %s", pssbam_last_error());
+                EF.failed = 1;
+                return -1;
+            }
         EF.genome_set = 1;
         EF.t_genome_set = frontend_now_s() - EF.t0;
         EF.t_genome_set_dur = frontend_now_s() - t;
     }
     return 1;
-fail:
-    snprintf(EF.err, sizeof EF.err, "GPU engine: %s", pssbam_last_error());
-    EF.failed = 1;
-    return -1;
+}
+
+static void early_engines_done(void)
+{
+    pthread_mutex_lock(&EF.mu);
+    EF.engines_done = 1;
+    pthread_cond_broadcast(&EF.cv);
+    pthread_mutex_unlock(&EF.mu);
 }
 
 static int feed_run(int n_gpus);
+
+static void *reserve_main(void *arg)
+{
+    const int n = (int)(intptr_t)arg, have = pssbam_device_count();
+    for (int g = 0; g < n && g < (have > 0 ? have : 1); g++) (void)pssbam_feed_reserve(g); /* best effort */
+    return NULL;
+}
 
 static void early_feed_main(void)
 {
     const int n = env_gpu_count(); /* the first HIP call: runtime start-up happens here */
     EF.t_hip = frontend_now_s() - EF.t0;
+    if (!getenv("PSSBAM_OVERSUBSCRIBE")) { /* the feed's device buffers, beside the engine set-up below (detached: it only allocates) */
+        pthread_t th;
+        if (pthread_create(&th, NULL, reserve_main, (void *)(intptr_t)n) == 0) pthread_detach(th);
+    }
     const bam_header *h = bam_reader_header(early_rd);
     const int have = pssbam_device_count();
     for (int g = 0; g < n; g++) {
@@ -97,12 +119,14 @@ static void early_feed_main(void)
             snprintf(EF.err, sizeof EF.err, "GPU engine %d: %s", g, pssbam_last_error());
             EF.failed = 1;
             EF.n_gpus = g + (EF.eng[g] != NULL);
+            early_engines_done();
             return;
         }
         EF.n_gpus = g + 1;
     }
     EF.engines_ok = 1;
     EF.t_engines = frontend_now_s() - EF.t0;
+    early_engines_done();
     { /* the light reader has inflated the file's first records on the host: the engines size their staged
        * record prefix from them (no read-back from the device later) */
         const uint8_t *r0;
@@ -198,9 +222,66 @@ static int same_config(const pssbam_config *a, const pssbam_config *b)
              a->kmer.max_read_len == b->kmer.max_read_len && a->kmer.merged_only == b->kmer.merged_only));
 }
 
+/* ---- the exit that does not make the caller wait ---------------------------------------------------------------
+ * Once the reports are on disk the command has nothing left to say, but the kernel still needs 0.2-0.3 s to take the
+ * process apart (five hardware queues, ~30 GB of device buffers and their page tables, pinned staging slots -- measured
+ * with tools/probe/exit_probe.hip and tools/feed_scan.py, profiles/r03_exit_teardown.txt): a third of the whole
+ * command on the 200 M-read shape.  So the work runs in a CHILD forked at the very top of main(), before any thread
+ * or HIP call exists; the process the caller started only waits for one byte -- the exit status, sent when the
+ * tables are written -- and returns it at once, while the child is dismantled in the background.  A child that
+ * ends without sending it (a diagnosed exit(1), a signal) is waited for and its status / signal relayed.
+ * PSSBAM_DETACH_EXIT=0 keeps everything in one process (the default under LD_PRELOAD: profilers and sanitizers
+ * bring the GPU runtime up before main, and a fork behind that is not safe). */
+static int detach_fd = -1;
+
+void frontend_detach_start(void)
+{
+    const char *v = getenv("PSSBAM_DETACH_EXIT"), *pre = getenv("LD_PRELOAD");
+    if (v ? atoi(v) == 0 : (pre && *pre)) return;
+    int fds[2];
+    if (pipe(fds) != 0) return;
+    fflush(NULL);
+    const pid_t pid = fork();
+    if (pid < 0) {
+        close(fds[0]);
+        close(fds[1]);
+        return;
+    }
+    if (pid == 0) { /* the worker: carries on into main() */
+        close(fds[0]);
+        (void)fcntl(fds[1], F_SETFD, FD_CLOEXEC);
+        detach_fd = fds[1];
+        return;
+    }
+    close(fds[1]);
+    unsigned char st = 0;
+    ssize_t n;
+    do n = read(fds[0], &st, 1);
+    while (n < 0 && errno == EINTR);
+    if (n == 1) _exit(st); /* the worker's tables are on disk and everything it had to print is printed */
+    int ws = 0;
+    while (waitpid(pid, &ws, 0) < 0 && errno == EINTR) {}
+    if (WIFSIGNALED(ws)) {
+        signal(WTERMSIG(ws), SIG_DFL);
+        kill(getpid(), WTERMSIG(ws));
+    }
+    _exit(WIFEXITED(ws) ? WEXITSTATUS(ws) : 1);
+}
+
 void front_end_exit(int status)
 {
     fflush(NULL);
+    if (detach_fd >= 0) { /* releases the caller; what follows is only the teardown */
+        const unsigned char st = (unsigned char)status;
+        if (write(detach_fd, &st, 1) != 1) {}
+        close(detach_fd);
+        detach_fd = -1;
+        /* a caller that reads our output through pipes waits for their END, not only for the process it started:
+         * the address space (and with it the GPU context) goes before the kernel closes a dying process's files */
+        close(0);
+        close(1);
+        close(2);
+    }
     if (frontend_fast_exit) _exit(status);
     exit(status);
 }
@@ -286,8 +367,24 @@ int run_tally(const pssbam_config *cfg, Genome *genome, const char *aln_path, in
     if (warmup_running) { /* HIP is needed from here on; the helper thread may be feeding already */
         const int mine = EF.want && is_bam && strcmp(early_path, aln_path) == 0 && same_config(cfg, &EF.cfg) && device_feed;
         if (EF.want) {
+            int upload_ok = 0;
+            if (mine) { /* the engines exist a few dozen ms after the runtime is up: normally long before the FASTA is in */
+                pthread_mutex_lock(&EF.mu);
+                while (!EF.engines_done) pthread_cond_wait(&EF.cv, &EF.mu);
+                pthread_mutex_unlock(&EF.mu);
+                upload_ok = EF.engines_ok;
+                const double tu = now_s();
+                /* every GPU's upload is enqueued before any is waited for: the links run side by side, and the
+                 * helper thread keeps feeding compressed blocks to the same engines meanwhile */
+                for (int g = 0; g < EF.n_gpus && upload_ok; g++)
+                    if (pssbam_engine_set_genome_async(EF.eng[g], genome)) {
+                        snprintf(EF.err, sizeof EF.err, "GPU engine %d: %s", g, pssbam_last_error());
+                        upload_ok = 0;
+                    }
+                EF.t_upload_dur = now_s() - tu;
+            }
             pthread_mutex_lock(&EF.mu);
-            if (mine) { EF.genome = genome; EF.posted = 1; }
+            if (mine && upload_ok) EF.posted = 1;
             else EF.abandon = 1;
             EF.t_posted = now_s() - EF.t0;
             pthread_cond_broadcast(&EF.cv);
@@ -295,7 +392,7 @@ int run_tally(const pssbam_config *cfg, Genome *genome, const char *aln_path, in
         }
         pthread_join(warmup_thread, NULL);
         warmup_running = 0;
-        if (EF.want && mine && EF.engines_ok && !EF.failed) {
+        if (EF.want && mine && EF.engines_ok && !EF.failed && EF.posted) {
             adopted = 1;
             n_gpus = EF.n_gpus;
             for (int g = 0; g < n_gpus; g++) eng[g] = EF.eng[g];
@@ -346,7 +443,7 @@ int run_tally(const pssbam_config *cfg, Genome *genome, const char *aln_path, in
         if (!EF.genome_set) { /* the feed ended before it looked at the gate (a file it does not take) */
             const bam_header *h = bam_reader_header(rd);
             for (int g = 0; g < n_gpus; g++)
-                if (pssbam_engine_set_genome(eng[g], genome) || pssbam_engine_set_references(eng[g], h->n_ref, (const char *const *)h->ref_name)) {
+                if (pssbam_engine_set_references(eng[g], h->n_ref, (const char *const *)h->ref_name)) {
                     fprintf(stderr, "Error: GPU engine %d: %s\n", g, pssbam_last_error());
                     goto done;
                 }
@@ -354,9 +451,9 @@ int run_tally(const pssbam_config *cfg, Genome *genome, const char *aln_path, in
         refs_sent = bam_reader_header(rd)->n_ref;
         dfs = EF.dfs;
         if (verbose)
-            fprintf(stderr, "[pssbam] early feed (helper thread, seconds after start-up began): HIP runtime up %.3f, engines %.3f, genome posted %.3f, "
-                            "genome + references on the engines %.3f (took %.3f), feed drained %.3f\n", EF.t_hip, EF.t_engines, EF.t_posted,
-                    EF.t_genome_set, EF.t_genome_set_dur, EF.t_feed_end);
+            fprintf(stderr, "[pssbam] early feed (helper thread, seconds after start-up began): HIP runtime up %.3f, engines %.3f, genome upload "
+                            "enqueued %.3f (took this thread %.3f), references set + put-off tallies launched %.3f (took %.3f), feed drained %.3f\n",
+                    EF.t_hip, EF.t_engines, EF.t_posted, EF.t_upload_dur, EF.t_genome_set, EF.t_genome_set_dur, EF.t_feed_end);
     } else {
         for (int g = 0; g < n_gpus; g++) {
             pssbam_config c = *cfg;
@@ -556,8 +653,8 @@ int run_tally(const pssbam_config *cfg, Genome *genome, const char *aln_path, in
     rc = 0;
 done:
     t_mark = now_s();
-    device_feed_prefetch_cancel(); /* (a loader opened ahead of time that no feed took over) */
     if (!(frontend_fast_exit && rc == 0)) {
+        device_feed_prefetch_cancel(); /* a loader opened ahead of time that no feed took over; the staging slots of one that ran */
         for (int g = 0; g < n_gpus; g++)
             if (eng[g]) pssbam_engine_destroy(eng[g]);
         if (registered) pssbam_host_unregister(buf_base);

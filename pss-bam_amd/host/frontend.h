@@ -34,6 +34,11 @@ int run_tally(const pssbam_config *cfg, Genome *genome, const char *aln_path, in
  * fasta_path (may be NULL) only sizes the device memory left alone for the genome.  aln_path may be NULL. */
 void frontend_warmup_start(const pssbam_config *cfg, const char *aln_path, const char *fasta_path);
 
+/* First statement of a front end's main(): forks the worker that runs the rest of main(); the process the caller
+ * started returns the worker's exit status as soon as front_end_exit() sends it, without waiting for the worker's
+ * teardown (frontend.c; PSSBAM_DETACH_EXIT=0 or a non-empty LD_PRELOAD: no fork). */
+void frontend_detach_start(void);
+
 extern int frontend_fast_exit;
 void front_end_exit(int status);
 void run_result_free(run_result *res);

@@ -23,7 +23,9 @@
 
 int main(int argc, char *argv[])
 {
-    const double t_main = frontend_now_s(), age_main = frontend_process_age_s();
+    const double age_main = frontend_process_age_s();
+    frontend_detach_start();   /* the caller gets its prompt back when the reports are written, not when 30 GB of device buffers are gone */
+    const double t_main = frontend_now_s();
     int region_len = 15, min_mq = 0, merged_only = 0, option;
     unsigned long min_read_len = 0, max_read_len = 250000000;
     const char *up_ctx = "ACGT", *down_ctx = "ACGT";
@@ -131,8 +133,8 @@ int main(int argc, char *argv[])
                     ? "  (more than 1 % of the records were longer than the staged prefix and took the one-lane path: slower, same tables)" : "");
         fprintf(stderr, "[pssbam] gpus=%d inflate_s=%.3f total_s=%.3f\n", res.n_gpus, res.inflate_s, res.total_s);
         fprintf(stderr, "[pssbam] main() to reports written: %.3f s\n", frontend_now_s() - t_main);
-        fprintf(stderr, "[pssbam] process creation to main(): %.2f s (exec + dynamic loading); process creation to reports written: %.2f s\n", age_main,
-                frontend_process_age_s());
+        fprintf(stderr, "[pssbam] process creation to main(): %.2f s (exec + dynamic loading); main() to here %.3f s\n", age_main,
+                frontend_now_s() - t_main);
     }
     if (frontend_fast_exit) { /* nothing left to do but to hand the memory back: let the OS */
         fprintf(stderr, "Done.\n");

@@ -454,7 +454,7 @@ def test_feed_ahead_of_the_genome(pkg, tmp_path, monkeypatch):
     record index run at once, the tally launches follow when the genome arrives.  Same tables as the serial order;
     with a ring that may not grow (PSSBAM_FEED_MAX_SLOTS) the engine answers PSSBAM_EBUSY, takes nothing of the
     chunk, and carries on once the genome is set."""
-    contigs, refs, recs = tl.fuzz_dataset(515, 6000, with_rg=True)
+    contigs, refs, recs = tl.fuzz_dataset(515, 24000, with_rg=True)                      # ~9 MB of records
     bam = tmp_path / "a.bam"
     tl.write_bam(bam, refs, recs, level=6, rng=np.random.default_rng(8), block=4000)    # records cross blocks
     raw = np.frombuffer(bam.read_bytes(), dtype=np.uint8)
@@ -466,7 +466,7 @@ def test_feed_ahead_of_the_genome(pkg, tmp_path, monkeypatch):
     eng.submit(tl.raw_records(refs, recs))
     want = eng.finish()
     eng.close()
-    monkeypatch.setenv("PSSBAM_FEED_SUPER_BYTES", str(1 << 20))      # ~25 super-batches
+    monkeypatch.setenv("PSSBAM_FEED_SUPER_BYTES", str(1 << 20))      # ~9 super-batches
     for max_slots, batch in ((None, 1 << 30), ("2", 60000), ("1", 50000), ("40", 200000)):   # (ONE submit is never cut short: it may pass the cap)
         if max_slots:
             monkeypatch.setenv("PSSBAM_FEED_MAX_SLOTS", max_slots)
