@@ -123,8 +123,9 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-sample", type=int, default=2_000_000, help="reads timed on the host reference")
     ap.add_argument("--region-len", type=int, default=None, help="override the configuration's -r N (parity cases / large-N passes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-cores", type=int, default=1,
-                    help="> 1: also time one reference process per core on disjoint shards (SURVEY 8d's all-cores figure)")
+    ap.add_argument("--cpu-cores", type=int, default=0,
+                    help="processes of the all-cores CPU figure (SURVEY 8d: one reference process per core on disjoint shards); "
+                         "0 = the CPUs this job may use (cgroup cpu.max), 1 = skip it")
     ap.add_argument("--scale-genome", type=float, default=1.0)
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the counter reduce even with one rank")
     ap.add_argument("--no-weak-leg", action="store_true", help="N > 1, strong: skip the additional weak-scaling measurement")
@@ -191,6 +192,18 @@ class Workload:
                 a = b
         torch.cuda.synchronize()
         self.rec_bytes = sum(b[2] for b in self.blocks)
+
+
+def git_blob_id(path: Path) -> str:
+    """what `git hash-object` prints for the file (the GPU box has no .git)"""
+    import hashlib
+    data = path.read_bytes()
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+
+
+def kernel_blobs() -> dict:
+    d = ROOT / "pss-bam_amd" / "csrc"
+    return {n: git_blob_id(d / n) for n in ("tally_kernels.h", "record_decode.h")}
 
 
 def traffic_entry(config: str, unsorted: bool, klen, region_len: int, reads_per_launch: float):
@@ -406,7 +419,9 @@ def main():
         # the same launch priced by what the memory system actually moved (PMC), not by the algorithm
         out["roofline"]["traffic_GBps"] = traffic / (kernel_ms_per_launch / 1e3) / 1e9
         out["roofline"]["frac_of_traffic"] = out["roofline"]["traffic_GBps"] / HBM_PEAK_GBS
-        out["roofline"]["traffic_source"] = {k: en.get(k) for k in ("command", "git_sha", "reads_per_launch", "date")}
+        out["roofline"]["traffic_source"] = {k: en.get(k) for k in ("command", "git_sha", "reads_per_launch", "date", "kernel_blobs")}
+        # the PMC bytes were measured on THESE kernel sources? (a lookup, not a measurement of this run)
+        out["roofline"]["traffic_stale"] = en.get("kernel_blobs") != kernel_blobs()
     if use_dist:
         out["per_rank"] = [{"rank": r, "kernel_ms_per_launch": p[0], "launches": int(p[1]), "reads": int(p[2]),
                             "record_bytes": int(p[3])} for r, p in enumerate(m["per_rank"])]
@@ -430,7 +445,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"], out["parity_check"] = cpu_baseline(pkg, synth, eng, cfg, cd, region_len, klen,
-                                                                    min(args.cpu_sample, my_reads), names, args.cpu_cores)
+                                                                    min(args.cpu_sample, my_reads), names,
+                                                                    args.cpu_cores or min(worker_threads(), 32))
         except Exception as ex:  # the baseline must never sink the GPU number
             out["cpu_baseline"] = {"value": None, "unit": "reads/s", "cores": 1, "kind": "reference",
                                    "sample": f"failed: {ex!r}"}
@@ -442,8 +458,28 @@ def main():
             out["e2e"] = e2e_leg(pkg, synth, cd, region_len, args.e2e_reads or total_reads, total_reads, strong_counters, lay)
         except Exception as ex:
             out["e2e"] = {"error": repr(ex)}
+    # ---- N > 1: the command itself over all GPUs of the node (one process, one engine per GPU) ----------
+    if world > 1 and not args.no_e2e and not klen and not args.unsorted and args.config != "C1":
+        flag = Path(tempfile.gettempdir()) / f"pssbam_e2e_done_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}"
+        if rank == 0:
+            try:
+                out["e2e"] = e2e_multi(pkg, synth, cd, region_len, args.e2e_reads or total_reads, total_reads, strong_counters, lay, world)
+            except Exception as ex:
+                out["e2e"] = {"error": repr(ex)}
+            flag.write_text("done")
+        else:   # the other ranks keep their hands off the GPUs meanwhile (no collective pending: a host-side wait)
+            t_wait = time.time()
+            while not flag.exists() and time.time() - t_wait < 3000:
+                time.sleep(0.2)
     if rank == 0:
         print(json.dumps(out), flush=True)
+    if use_dist and world > 1:
+        dist.barrier()
+        if rank == 0:
+            try:
+                (Path(tempfile.gettempdir()) / f"pssbam_e2e_done_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}").unlink()
+            except OSError:
+                pass
     eng.close()
     if use_dist:
         dist.destroy_process_group()
@@ -495,6 +531,9 @@ def e2e_leg(pkg, synth, cd, region_len, n_reads, resident_reads, resident_counte
             if r[0].returncode != 0:
                 return {"error": r[0].stderr[-1500:]}
         pr, wall = runs[1]
+        # the same with the teardown in the foreground (by default the process the caller started returns when the
+        # reports are written and a forked worker is dismantled behind it: host/frontend.c frontend_detach_start)
+        pr_fg, wall_fg = run_cli({"PSSBAM_DETACH_EXIT": "0"}, "out_fg")
         grab = lambda pat: (lambda mm: mm.group(1) if mm else None)(re.search(pat, pr.stderr))
         tally_s = float(grab(r"total_s=([\d.]+)") or 0)
         stages = {}
@@ -503,6 +542,8 @@ def e2e_leg(pkg, synth, cd, region_len, n_reads, resident_reads, resident_counte
             if txt:
                 for k, v in re.findall(r"([A-Za-z+()\-_0-9 ]+?) ([\d.]+)(?: |$)", txt):
                     stages[k.strip()] = float(v)
+        busy = re.search(r"gpu busy: inflate\+crc\+index ([\d.]+) tally ([\d.]+) s", pr.stderr)
+        gpu_busy_s = (float(busy.group(1)) + float(busy.group(2)) + 0.006) if busy else None   # + genome encode / pack kernels
         got_f, got_r = tl.parse_counts_text((tmp / "out.pss.counts.txt").read_text())
         check = None
         if n_reads == resident_reads:
@@ -514,12 +555,31 @@ def e2e_leg(pkg, synth, cd, region_len, n_reads, resident_reads, resident_counte
         # The named configurations have constant QUAL, which DEFLATE turns into one long match per read.
         # A second, smaller file with 40-level quality strings at level 6 shows the same command on what a
         # sequencer's BAM looks like to the feed: ~4x the compressed bytes per read, a literal-heavy stream.
-        real = None
         bam_bytes = bam.stat().st_size
+        # SURVEY 8d asks for the uncompressed-BGZF case separately: level 0, every record byte crosses PCIe
+        level0 = None
+        n_l0 = min(n_reads, int(os.environ.get("PSSBAM_E2E_LEVEL0_READS", "50000000")))
+        if n_l0 > 0 and shutil.disk_usage(tmp).free > 300.0 * n_l0 + bam_bytes:
+            try:
+                bam.unlink(missing_ok=True)
+                t = time.perf_counter()
+                synth.bam_file_host(cfg, 0, n_l0, bam, level=0, threads=threads)
+                t_bam0 = time.perf_counter() - t
+                r0 = sorted((run_cli({}, "l0") for _ in range(3)), key=lambda r: r[1])
+                if all(r[0].returncode == 0 for r in r0):
+                    level0 = {"what": "the same command on a level-0 (stored) BGZF BAM: PCIe carries every record byte",
+                              "reads": n_l0, "bam_bytes": bam.stat().st_size, "wall_s": r0[1][1], "reads_per_s": n_l0 / r0[1][1],
+                              "wall_s_runs": [r[1] for r in r0], "wall_s_is": "median of 3 runs", "workload_gen_s": t_bam0,
+                              "device_feed": (lambda mm: mm.group(1) if mm else None)(re.search(r"device feed: (.*)\n", r0[1][0].stderr))}
+                else:
+                    level0 = {"error": r0[0][0].stderr[-500:]}
+            except Exception as ex:
+                level0 = {"error": repr(ex)}
+        real = None
         n_real = min(n_reads, int(os.environ.get("PSSBAM_E2E_REAL_READS", "50000000")))
         if n_real > 0:
             try:
-                bam.unlink()
+                bam.unlink(missing_ok=True)
                 t = time.perf_counter()
                 synth.bam_file_host(cfg, 0, n_real, bam, level=6, threads=threads, quals="full")
                 t_bam2 = time.perf_counter() - t
@@ -543,6 +603,13 @@ def e2e_leg(pkg, synth, cd, region_len, n_reads, resident_reads, resident_counte
             "reads": n_reads, "bam_bytes": bam_bytes, "fasta_bytes": fa.stat().st_size,
             "deflate_level": 1, "block_layout": "htslib", "host_cpus_effective": effective_cpus(),
             "wall_s": wall, "reads_per_s": n_reads / wall, "wall_s_runs": [r[1] for r in runs], "wall_s_is": "median of 3 runs",
+            "gpu_busy_s": gpu_busy_s, "gpu_busy_frac": gpu_busy_s / wall if gpu_busy_s else None,
+            "gpu_busy_is": "sum of kernel time (HIP events around inflate + CRC + record index, and around every tally launch; + 6 ms "
+                           "genome encode / 4-bit pack) of the median run, over its wall seconds",
+            "wall_s_foreground_exit": wall_fg if pr_fg.returncode == 0 else None,
+            "wall_s_note": "wall_s = until the process the caller started returns (reports written; a forked worker is torn down "
+                           "behind it); wall_s_foreground_exit = PSSBAM_DETACH_EXIT=0, one process, teardown included",
+            "early_feed": grab(r"early feed \(helper thread[^:]*\): (.*)\n"),
             "tally_phase_s": tally_s, "reads_per_s_tally_phase": n_reads / tally_s if tally_s else None,
             "fasta_load_s": stages.get("fasta load"), "stages_s": stages,
             "feed": "device inflate" if "device feed:" in pr.stderr and "falling back" not in pr.stderr else "host inflate",
@@ -554,8 +621,66 @@ def e2e_leg(pkg, synth, cd, region_len, n_reads, resident_reads, resident_counte
                                  if pr_h.returncode == 0 else {"error": pr_h.stderr[-500:]}),
             "tables_check": check, "note": note,
             "workload_gen_s": {"fasta": t_fa, "bam": t_bam},
-            "real_quals": real,
+            "real_quals": real, "level0": level0,
         }
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def e2e_multi(pkg, synth, cd, region_len, n_reads, resident_reads, resident_counters, lay, world):
+    """N > 1: `PSSBAM_NGPU=N bin/pss-bam` on the generated level-1 BAM + FASTA of the benchmarked shape -- ONE process
+    driving one engine per GPU: the compressed file is dealt in runs of whole super-batches, every GPU inflates, indexes
+    and tallies its runs, pssbam_reduce_counters sums the counter blocks with one grouped ncclReduce over xGMI
+    (csrc/engine.hip).  Run on rank 0 while the other ranks wait on the host; tables checked against the reduced
+    tally of the distributed measurement when the read counts agree."""
+    import numpy as np
+    import pssbam_testlib as tl
+
+    threads = worker_threads()
+    tmp = Path(tempfile.mkdtemp(prefix="pssbam_e2e_", dir=os.environ.get("PSSBAM_E2E_DIR", os.environ.get("TMPDIR", "/tmp"))))
+    try:
+        d = dict(cd)
+        d["sorted_"] = True
+        d["n_reads"] = resident_reads
+        free = shutil.disk_usage(tmp).free
+        est = 3.2e9 * (sum(d["contig_lens"]) / 3.1e9) + 60.0 * n_reads
+        note = None
+        if est > 0.8 * free:
+            n_reads = int(max(1_000_000, (0.8 * free - 3.3e9) / 60.0))
+            note = f"bounded by free disk: {n_reads} reads"
+        cfg = synth.make_cfg(**d)
+        fa, bam = tmp / "ref.fa", tmp / "reads.bam"
+        synth.fasta_host(cfg, fa, threads=threads)
+        synth.bam_file_host(cfg, 0, n_reads, bam, level=1, threads=threads)
+
+        def run_cli(extra):
+            t = time.perf_counter()
+            pr = subprocess.run([str(pkg.PKG_DIR / "bin" / "pss-bam"), "-F", str(fa), "-B", str(bam), "-o", str(tmp / "out"), "-r", str(region_len)],
+                                capture_output=True, text=True, env={**os.environ, "PSSBAM_STATS": "1", "PSSBAM_NGPU": str(world), **extra}, timeout=1500)
+            return pr, time.perf_counter() - t
+        runs = sorted((run_cli({}) for _ in range(3)), key=lambda r: r[1])
+        for r in runs:
+            if r[0].returncode != 0:
+                return {"error": r[0].stderr[-1500:]}
+        pr, wall = runs[1]
+        grab = lambda pat: (lambda mm: mm.group(1) if mm else None)(re.search(pat, pr.stderr))
+        got_f, got_r = tl.parse_counts_text((tmp / "out.pss.counts.txt").read_text())
+        check = None
+        if n_reads == resident_reads:
+            rows = lay["rows"]
+            ok = bool(np.array_equal(got_f, resident_counters[lay["fwd"]:lay["fwd"] + rows * 16].reshape(rows, 16)) and
+                      np.array_equal(got_r, resident_counters[lay["rev"]:lay["rev"] + rows * 16].reshape(rows, 16)))
+            check = "tables identical to the reduced tally of the distributed measurement" if ok else "MISMATCH vs the reduced tally"
+        one, wall_one = run_cli({"PSSBAM_NGPU": "1"})
+        per = grab(r"submits per engine: (.*)\n")
+        return {"command": f"PSSBAM_NGPU={world} bin/pss-bam -F ref.fa -B reads.bam -o out -r {region_len}", "reads": n_reads,
+                "bam_bytes": bam.stat().st_size, "gpus": int(grab(r"gpus=(\d+)") or 0), "wall_s": wall, "reads_per_s": n_reads / wall,
+                "wall_s_runs": [r[1] for r in runs], "wall_s_is": "median of 3 runs",
+                "submits_per_engine": [int(x) for x in per.split()] if per else None, "device_feed": grab(r"device feed: (.*)\n"),
+                "feed": "device inflate" if "device feed:" in pr.stderr and "falling back" not in pr.stderr else "host inflate",
+                "gpu_busy": grab(r"gpu busy: (.*)\n"), "early_feed": grab(r"early feed \(helper thread[^:]*\): (.*)\n"),
+                "one_gpu_same_file": {"wall_s": wall_one, "reads_per_s": n_reads / wall_one} if one.returncode == 0 else {"error": one.stderr[-300:]},
+                "tables_check": check, "note": note}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
@@ -623,8 +748,11 @@ def cpu_baseline(pkg, synth, eng, cfg, cd, region_len, klen, n_sample, names, cp
               else f"MISMATCH vs {kind} on the CPU sample")
     out = {"value": value, "unit": "reads/s", "cores": 1, "kind": kind, "sample": sample}
     if cpu_cores > 1 and have_ref:
-        out["all_cores"] = cpu_all_cores(pkg, synth, scfg, region_len, names, tmp, o, cpu_cores,
-                                         max(200_000, n_sample // 4))
+        try:   # bounded: <= 500 k reads per process, so the default run stays within minutes
+            out["all_cores"] = cpu_all_cores(pkg, synth, scfg, region_len, names, tmp, o, cpu_cores,
+                                             min(500_000, max(100_000, n_sample // 4), max(1, int(scfg.n_reads) // cpu_cores)))
+        except Exception as ex:
+            out["all_cores"] = {"error": repr(ex)}
     shutil.rmtree(tmp, ignore_errors=True)
     return (out, parity)
 

@@ -314,7 +314,7 @@ int run_device_feed(pssbam_engine *const *eng, int n_gpus, const char *path, siz
     long n_prescanned = 0;
     size_t pos = 0;                /* file offset of the next BGZF block */
     size_t skip = header_bytes;    /* inflated bytes still to skip in front of the first record */
-    uint64_t n_submits = 0;
+    uint64_t n_submits = 0, submits_of[64] = {0};
     int last_g = -1;
     for (long k = 0; k < L->n_chunks; k++) {
         stage_t *s = &L->st[k % L->n_st];
@@ -399,6 +399,7 @@ int run_device_feed(pssbam_engine *const *eng, int n_gpus, const char *path, siz
                 if (!gate_open) n_submits_ahead++;
                 skip = 0;
                 n_submits++;
+                submits_of[g & 63]++;
                 fs->compressed_bytes += end_in - base_in;
                 const int q = (fifo_head + fifo_len) % 128;
                 fifo[q].chunk = k; fifo[q].g = g; fifo[q].ticket = ticket;
@@ -449,6 +450,11 @@ int run_device_feed(pssbam_engine *const *eng, int n_gpus, const char *path, siz
                 (unsigned long long)n_submits, fs->compressed_bytes * 1e-9, fs->inflated_bytes * 1e-9, fs->inflate_ms * 1e-3,
                 fs->inflate_ms > 0 ? fs->inflated_bytes * 1e-6 / fs->inflate_ms : 0.0, n_th, L->n_st, L->W >> 20,
                 fs->fallback ? "; records cross BGZF blocks -> host reader" : "");
+    if (verbose && n_gpus > 1) {
+        fprintf(stderr, "[pssbam] device feed, submits per engine:");
+        for (int g = 0; g < n_gpus; g++) fprintf(stderr, " %llu", (unsigned long long)submits_of[g & 63]);
+        fputc('\n', stderr);
+    }
     if (verbose)
         fprintf(stderr, "[pssbam] device feed, this thread: waiting for loaders %.3f, block-header walk %.3f (%ld of %ld windows walked by "
                         "their loader), submit (incl. waiting for a free slot) %.3f, waiting for copies %.3f, waiting for the genome %.3f s "

@@ -636,6 +636,8 @@ int run_tally(const pssbam_config *cfg, Genome *genome, const char *aln_path, in
             if (pssbam_engine_phase_times(eng[g], &a, &b, &c, &d) == 0) { h2d += a; bytes += b; ker += c; launches += d; }
         }
         fprintf(stderr, "[pssbam] device: h2d %.3f kernel %.3f s\n", h2d * 1e-3, ker * 1e-3);
+        /* what the GPU(s) spent in kernels, all engines summed (genome encode + 4-bit pack: ~6 ms per GPU, not timed) */
+        fprintf(stderr, "[pssbam] gpu busy: inflate+crc+index %.3f tally %.3f s over %d engine(s)\n", fed_on_device ? dfs.inflate_ms * 1e-3 : 0.0, ker * 1e-3, n_gpus);
         fprintf(stderr, "[pssbam] device detail: %.2f GB copied (%.1f GB/s while copying), %llu tally launches\n", bytes * 1e-9,
                 h2d > 0 ? bytes * 1e-6 / h2d : 0.0, (unsigned long long)launches);
     }
@@ -657,6 +659,7 @@ done:
         device_feed_prefetch_cancel(); /* a loader opened ahead of time that no feed took over; the staging slots of one that ran */
         for (int g = 0; g < n_gpus; g++)
             if (eng[g]) pssbam_engine_destroy(eng[g]);
+        for (int g = 0; g < n_gpus; g++) (void)pssbam_feed_release(g); /* reserved feed buffers no engine took */
         if (registered) pssbam_host_unregister(buf_base);
         bam_reader_close(rd);
         sam_reader_close(sd);

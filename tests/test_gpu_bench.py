@@ -35,6 +35,10 @@ def test_bench_force_dist_one_rank_rccl():
     assert w["scaling"] == "weak" and w["reads_per_gpu"] == 2_000_000 and w["value"] > 1e8 and w["reduce_ms"] > 0
     assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1.0
     assert d["cpu_baseline"]["cores"] == 1 and "bit-exact" in d["parity_check"]
+    ac = d["cpu_baseline"]["all_cores"]                              # one reference process per core, by default
+    assert "error" not in ac, ac
+    assert ac["processes"] >= 2 and ac["cores"] > 1 and ac["value"] > 0 and "bit-exact" in ac["parity_check"]
+    assert d["roofline"]["traffic"] is None or isinstance(d["roofline"]["traffic_stale"], bool)
 
 
 def test_bench_bare_multi_gpu_launch_is_decided_before_any_gpu_call():
@@ -56,6 +60,8 @@ def test_bench_e2e_leg_small():
     assert e["reads"] == 3_000_000 and e["tables_check"].startswith("tables identical")
     assert e["wall_s"] > 0 and e["fasta_load_s"] is not None and len(e["wall_s_runs"]) == 3
     assert e["host_inflate_run"]["tables_identical"]
+    assert 0 < e["gpu_busy_s"] < e["wall_s_foreground_exit"] and e["wall_s_foreground_exit"] > 0 and e["early_feed"]
+    assert "error" not in e["level0"] and e["level0"]["reads"] == 3_000_000 and e["level0"]["bam_bytes"] > 5 * e["bam_bytes"]
     r = e["real_quals"]   # the same command on a BAM with sequencer-like quality strings
     assert "error" not in r, r
     assert r["reads"] == 3_000_000 and r["host_inflate_run"]["tables_identical"] and r["bam_bytes"] > 2 * e["bam_bytes"]
