@@ -517,6 +517,7 @@ def e2e_leg(pkg, synth, cd, region_len, n_reads, resident_reads, resident_counte
         t_bam = time.perf_counter() - t
         def run_cli(extra_env, prefix):
             env = {**os.environ, "PSSBAM_STATS": "1", **extra_env}
+            time.sleep(1.0)   # the previous run's teardown (a forked worker, 30 GB of device buffers) is out of the way, as for a user's command
             t = time.perf_counter()
             pr = subprocess.run([str(pkg.PKG_DIR / "bin" / "pss-bam"), "-F", str(fa), "-B", str(bam), "-o", str(tmp / prefix),
                                  "-r", str(region_len)], capture_output=True, text=True, env=env, timeout=1500)
@@ -654,6 +655,7 @@ def e2e_multi(pkg, synth, cd, region_len, n_reads, resident_reads, resident_coun
         synth.bam_file_host(cfg, 0, n_reads, bam, level=1, threads=threads)
 
         def run_cli(extra):
+            time.sleep(1.0)   # (as in e2e_leg)
             t = time.perf_counter()
             pr = subprocess.run([str(pkg.PKG_DIR / "bin" / "pss-bam"), "-F", str(fa), "-B", str(bam), "-o", str(tmp / "out"), "-r", str(region_len)],
                                 capture_output=True, text=True, env={**os.environ, "PSSBAM_STATS": "1", "PSSBAM_NGPU": str(world), **extra}, timeout=1500)

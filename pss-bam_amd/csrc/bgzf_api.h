@@ -90,6 +90,9 @@ static int launch_inflate(hipStream_t st, const void *d_comp, uint64_t comp_byte
     if (!attr_set[dev & 63]) {
         HIP_TRY(hipFuncSetAttribute((const void *)pssbam::bgzf_inflate_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pssbam::INF_LDS_BYTES));
         HIP_TRY(hipFuncSetAttribute((const void *)pssbam::bgzf_inflate_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pssbam::INF_LDS_BYTES_DEFER));
+        HIP_TRY(hipFuncSetAttribute((const void *)pssbam::bgzf_inflate_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pssbam::INF_LDS_BYTES_DEFER));
+        HIP_TRY(hipFuncSetAttribute((const void *)pssbam::bgzf_inflate_kernel<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pssbam::INF_LDS_BYTES_DEFER));
+        HIP_TRY(hipFuncSetAttribute((const void *)pssbam::bgzf_inflate_kernel<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pssbam::INF_LDS_BYTES_DEFER));
         attr_set[dev & 63] = true;
     }
     if (loop == -2) loop = 0;   // (not negotiable)
@@ -103,7 +106,29 @@ static int launch_inflate(hipStream_t st, const void *d_comp, uint64_t comp_byte
     // literal runs, literal-dominated ones with longer ones
     uint32_t lit_run = out_bytes && out_bytes >= 8ull * comp_bytes ? 4u : 6u;
     if (const char *lr = getenv("PSSBAM_INFLATE_RUN")) lit_run = (uint32_t)std::max(1, atoi(lr));
-    if (loop > 0)
+    const char *pv = getenv("PSSBAM_INFLATE_PIECES");
+    const bool pieces = pv ? atoi(pv) != 0 : true;   // bounded work per lane and step (csrc/inflate_kernels.h INF_PIECE)
+    if (loop > 0 && getenv("PSSBAM_INFLATE_STAMPS")) {   // diagnostic build: where the cycles of a step go (tools/inflate_stamps.sh)
+        static unsigned long long *d_dbg = nullptr;
+        if (!d_dbg) HIP_TRY(hipMalloc(&d_dbg, 8 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemsetAsync(d_dbg, 0, 8 * sizeof(unsigned long long), st));
+        if (pieces)
+            hipLaunchKernelGGL((pssbam::bgzf_inflate_kernel<true, true, true>), dim3(grid), dim3(pssbam::INF_WAVE), pssbam::INF_LDS_BYTES_DEFER, st, (const uint8_t *)d_comp,
+                               comp_bytes, (pssbam::BgzfBlock *)d_blocks, n_blocks, (uint8_t *)d_out, lit_run, d_dbg);
+        else
+            hipLaunchKernelGGL((pssbam::bgzf_inflate_kernel<true, false, true>), dim3(grid), dim3(pssbam::INF_WAVE), pssbam::INF_LDS_BYTES_DEFER, st, (const uint8_t *)d_comp,
+                               comp_bytes, (pssbam::BgzfBlock *)d_blocks, n_blocks, (uint8_t *)d_out, lit_run, d_dbg);
+        unsigned long long h[8];
+        HIP_TRY(hipMemcpyAsync(h, d_dbg, sizeof h, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        const double L = (double)std::max<unsigned long long>(h[3], 1);
+        fprintf(stderr, "[pssbam] inflate stamps (pieces %d; lane sums, shader cycles): steps %llu, per step: decode %.0f wait %.0f stores+copies %.0f cycles; lanes in a step %.1f of 64; "
+                        "literals per step %.2f; steps ending in an in-place copy %.3f; in-loop share of the lanes' kernel cycles %.3f\n", (int)pieces,
+                h[3], h[0] / L, h[1] / L, h[2] / L, h[4] / L, h[5] / L, h[6] / L, (double)(h[0] + h[1] + h[2]) / (double)std::max<unsigned long long>(h[7], 1));
+    } else if (loop > 0 && pieces)
+        hipLaunchKernelGGL((pssbam::bgzf_inflate_kernel<true, true>), dim3(grid), dim3(pssbam::INF_WAVE), pssbam::INF_LDS_BYTES_DEFER, st, (const uint8_t *)d_comp,
+                           comp_bytes, (pssbam::BgzfBlock *)d_blocks, n_blocks, (uint8_t *)d_out, lit_run);
+    else if (loop > 0)
         hipLaunchKernelGGL(pssbam::bgzf_inflate_kernel<true>, dim3(grid), dim3(pssbam::INF_WAVE), pssbam::INF_LDS_BYTES_DEFER, st, (const uint8_t *)d_comp,
                            comp_bytes, (pssbam::BgzfBlock *)d_blocks, n_blocks, (uint8_t *)d_out, lit_run);
     else
@@ -164,7 +189,7 @@ extern "C" int pssbam_bgzf_inflate_host(int device, const void *bgzf, uint64_t n
     };
 #define TRY_C(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { cleanup(); return fail(PSSBAM_EHIP, "%s failed: %s", #expr, hipGetErrorString(_e)); } } while (0)
     TRY_C(hipMalloc(&d_comp, nbytes + 16));
-    TRY_C(hipMalloc(&d_out, total + 64));   // (slack for the one-wait-per-step loop's requests)
+    TRY_C(hipMalloc(&d_out, total + 128));   // (slack for the one-wait-per-step loop's requests: up to 64 bytes past a block's end)
     TRY_C(hipMalloc(&d_blocks, (size_t)n * sizeof(pssbam_bgzf_block)));
     TRY_C(hipMemset(d_comp + nbytes, 0, 16));
     TRY_C(hipMemcpy(d_comp, bgzf, nbytes, hipMemcpyHostToDevice));

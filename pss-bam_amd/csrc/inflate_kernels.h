@@ -80,8 +80,19 @@ constexpr int INF_WAVES_PER_CU = 4;   // one per SIMD: 4 do what 5 do, or better
 // literals a lane may take per step.  DEFER: they travel in one register (<= 8), and the budget is a launch
 // parameter -- 4 suits match-dominated streams, 6 literal-dominated ones (profiles/r02_inflate_variants.txt)
 constexpr uint32_t INF_RUN_INPLACE = 4u, INF_RUN_DEFER_MAX = 8u;
-// landing planes of the DEFER loop: three times 16 bytes per lane behind the decode tables
-constexpr uint32_t INF_LAND_BYTES = 3u * 16u * INF_WAVE;
+// landing planes of the DEFER loop behind the decode tables: 16 bytes per lane each -- four for the source of a copy
+// piece (two without PIECES), one for the stream
+constexpr uint32_t INF_LAND_BYTES = 5u * 16u * INF_WAVE;
+// PIECES (the engine feed's default; PSSBAM_INFLATE_PIECES=0 for A/B): BOUNDED WORK PER LANE AND STEP.  Stamps around the
+// phases of a step (profiles/r03_inflate_step_stamps.txt) showed where a step's 11-15 thousand cycles went: 4.5-6.3 k in
+// the decode phase, ~30 in the wait (what was requested HAD arrived) and 4.7-10 k behind it -- because a copy that was
+// long (> 32 bytes: a BAM's SEQ and QUAL matches) or a run (QUAL: 150 bytes of period 1) was carried out IN PLACE, with
+// its own load round trips and store loops, by the lanes that had one while the other 60 waited: with 64 lanes SOME lane
+// has one at nearly every step, so every lane paid for it at every step.  Now a lane moves at most INF_PIECE bytes of a
+// copy per step, through the landing planes like a short copy: a long copy or run spans several steps, during which ITS
+// lane decodes nothing (its stream position and its literals wait) and the others go on.  Steps get shorter for all 64
+// lanes; a lane with a 150-byte copy spends three of them on it.
+constexpr uint32_t INF_PIECE = 64u;
 constexpr uint32_t INF_LDS_BYTES_DEFER = INF_LDS_BYTES + INF_LAND_BYTES;
 static_assert(INF_LDS_BYTES_DEFER * INF_WAVES_PER_CU <= 160u * 1024u, "the waves of the DEFER loop must fit the CU's LDS");
 
@@ -322,11 +333,24 @@ __device__ __forceinline__ void dma16_to_lds(uint32_t lds_base, const void *src)
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(src), "s"(m0v) : "memory");
 }
+// the low n (1..64) bytes of four 16-byte planes, in at most five store requests
+__device__ __forceinline__ void store_piece(uint8_t *p, uint4 a, uint4 b, uint4 c, uint4 d, uint32_t n) {
+    uint4 last = a;
+    if (n > 16u) { store_u128(p, a); p += 16; n -= 16u; last = b; }
+    if (n > 16u) { store_u128(p, b); p += 16; n -= 16u; last = c; }
+    if (n > 16u) { store_u128(p, c); p += 16; n -= 16u; last = d; }
+    store_tail16(p, (uint64_t)last.x | ((uint64_t)last.y << 32), (uint64_t)last.z | ((uint64_t)last.w << 32), n);
+}
 
 // One BGZF block by one lane.  Returns INF_*.  land: this wave's landing planes, lit_run: literals per step (DEFER only).
-template <bool DEFER>
+// STAMP: a diagnostic build of the DEFER loop (tools/inflate_stamps.py): shader-clock stamps around the phases of every step,
+// summed per lane into st[] -- [0] decode phase (requests .. wait), [1] the wait, [2] stores + classification + in-place
+// copies, [3] steps, [4] lanes of the wave that were in the step, [5] literals, [6] steps that ended in an in-place copy.
+// The stamp values go to a buffer of their own and feed nothing else.
+struct StepStamps { uint64_t v[8]; };
+template <bool DEFER, bool PIECES, bool STAMP = false>
 __device__ uint32_t inflate_block(const uint8_t *comp, uint64_t comp_bytes, const BgzfBlock &b, uint8_t *outbuf, const LaneLds &t,
-                                  uint8_t *land, uint32_t lane, uint32_t lit_run) {
+                                  uint8_t *land, uint32_t lane, uint32_t lit_run, StepStamps *st = nullptr) {
     uint8_t *out = outbuf + b.out_off;
     const uint32_t isize = b.isize;
     BitReader br;
@@ -492,17 +516,26 @@ __device__ uint32_t inflate_block(const uint8_t *comp, uint64_t comp_bytes, cons
             // copy's source has been stored (issued) before the request is; at the end of a deflate block
             // nothing is pending (its last step has no copy).
             const uint32_t land0 = (uint32_t)(uintptr_t)land;   // LDS byte address of the planes
-            const uint8_t *lsrc = comp;     // what (0) reads: the pending copy's source, else the head of the buffer
+            constexpr uint32_t STREAM_PLANE = 64u * INF_WAVE;    // (planes 0-3: the copy piece)
+            const uint8_t *lsrc = comp;     // what (0) reads: the pending piece's source, else the head of the buffer
             uint8_t *pdst = out;
-            uint32_t plen = 0, pdist = 0;   // pending copy; pdist != 0: a run of period pdist (< 8) seeded by the 8 bytes in front of pdst
+            uint32_t plen = 0, pdist = 0;   // pending piece; pdist != 0: a run of period pdist (< 8) seeded by the 8 bytes in front of pdst
+            uint32_t prem = 0, pcap = 0;    // PIECES: bytes of the copy behind the pending piece, and the most one piece may take
             for (;;) {
+                uint64_t ts0 = 0, ts1 = 0, ts2 = 0;
+                if constexpr (STAMP) ts0 = __builtin_amdgcn_s_memtime();
                 dma16_to_lds(land0, lsrc);
                 dma16_to_lds(land0 + 16u * INF_WAVE, lsrc + 16);
-                dma16_to_lds(land0 + 32u * INF_WAVE, br.request_addr());
+                if constexpr (PIECES) {
+                    dma16_to_lds(land0 + 32u * INF_WAVE, lsrc + 32);
+                    dma16_to_lds(land0 + 48u * INF_WAVE, lsrc + 48);
+                }
+                dma16_to_lds(land0 + STREAM_PLANE, br.request_addr());
+                const bool busy = PIECES && prem != 0u;   // this lane is in the middle of a copy: it decodes nothing this step
                 int sym = 512;   // 512: no token this step
                 uint32_t run = 0;
                 uint64_t lits = 0;
-                while (run < lit_run && br.avail() >= 64u) {   // (two literals and a token take at most 30 + 33 bits)
+                while (!busy && run < lit_run && br.avail() >= 64u) {   // (two literals and a token take at most 30 + 33 bits)
                     br.refill_nomem();
                     const LitPair lp = litlen_peek2(br, t, lu);
                     if (lp.a < 0) { sym = -1; break; }
@@ -541,25 +574,49 @@ __device__ uint32_t inflate_block(const uint8_t *comp, uint64_t comp_bytes, cons
                     }
                 }
                 // ---- (2): what (0) requested has had the decode phase to arrive
+                if constexpr (STAMP) ts1 = __builtin_amdgcn_s_memtime();
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if constexpr (STAMP) {
+                    ts2 = __builtin_amdgcn_s_memtime();
+                    st->v[0] += ts1 - ts0;
+                    st->v[1] += ts2 - ts1;
+                    st->v[3] += 1;
+                    st->v[4] += (uint64_t)__popcll(__ballot(1));
+                    st->v[5] += run;
+                }
                 if (plen) {
                     const uint4 pa = *(const uint4 *)(land + 16u * lane);
                     if (pdist) store_run(pdst, ((uint64_t)pa.z | ((uint64_t)pa.w << 32)) >> (8u * (8u - pdist)), pdist, plen);
-                    else if (plen > 16u) {
+                    else if constexpr (PIECES) {
+                        const uint4 pb = *(const uint4 *)(land + 16u * INF_WAVE + 16u * lane), pc = *(const uint4 *)(land + 32u * INF_WAVE + 16u * lane),
+                                    pd = *(const uint4 *)(land + 48u * INF_WAVE + 16u * lane);
+                        store_piece(pdst, pa, pb, pc, pd, plen);
+                    } else if (plen > 16u) {
                         const uint4 pb = *(const uint4 *)(land + 16u * INF_WAVE + 16u * lane);
                         store_u128(pdst, pa);
                         store_tail16(pdst + 16, (uint64_t)pb.x | ((uint64_t)pb.y << 32), (uint64_t)pb.z | ((uint64_t)pb.w << 32), plen - 16u);
                     } else store_tail16(pdst, (uint64_t)pa.x | ((uint64_t)pa.y << 32), (uint64_t)pa.z | ((uint64_t)pa.w << 32), plen);
-                    plen = 0;
+                    if (PIECES && prem) {   // the next piece of the same copy (a run's seed is re-read behind the bytes just stored)
+                        pdst += plen;
+                        lsrc = pdist ? pdst - 16 : lsrc + plen;
+                        plen = min(prem, pcap);
+                        prem -= plen;
+                    } else {
+                        plen = 0;
+                        lsrc = comp;
+                    }
                 }
-                br.take_group(*(const uint4 *)(land + 32u * INF_WAVE + 16u * lane));
+                br.take_group(*(const uint4 *)(land + STREAM_PLANE + 16u * lane));
                 if (run) {
                     if (run > isize - pos) return INF_OVERRUN;
                     store_tail(out + pos, lits, run);
                     pos += run;
                 }
-                if (sym == 256) { br.request(); break; }   // (the headers read the stream with ordinary loads again)
-                lsrc = comp;
+                if (sym == 256) {
+                    if constexpr (STAMP) st->v[2] += __builtin_amdgcn_s_memtime() - ts2;
+                    br.request();   // (the headers read the stream with ordinary loads again)
+                    break;
+                }
                 if (len) {
                     if (dist > pos) return INF_BAD_DISTANCE;
                     if (len > isize - pos) return INF_OVERRUN;
@@ -567,8 +624,16 @@ __device__ uint32_t inflate_block(const uint8_t *comp, uint64_t comp_bytes, cons
                     const uint8_t *src = dst - dist;
                     if (dist < 8u && pos >= 16u) {
                         lsrc = dst - 16;   // (the seed is the upper half of the first plane)
-                        pdst = dst; plen = len; pdist = dist;
-                    } else if (dist >= 8u && len <= 32u && dist >= len) {
+                        pdst = dst; pdist = dist;
+                        if constexpr (PIECES) { pcap = INF_PIECE; plen = min(len, pcap); prem = len - plen; }
+                        else plen = len;
+                    } else if (PIECES && dist >= 16u) {
+                        // pieces of <= 64 bytes, never longer than the distance: a piece's source lies wholly in front of its
+                        // destination, i.e. in bytes stored (issued) before its request is
+                        lsrc = src;
+                        pdst = dst; pdist = 0u;
+                        pcap = min(INF_PIECE, dist); plen = min(len, pcap); prem = len - plen;
+                    } else if (!PIECES && dist >= 8u && len <= 32u && dist >= len) {
                         // (the 32 bytes requested may run past dst by up to 24: not-yet-written bytes of this block, of
                         //  the next one or of the buffer's slack, none of which is stored)
                         lsrc = src;
@@ -594,8 +659,10 @@ __device__ uint32_t inflate_block(const uint8_t *comp, uint64_t comp_bytes, cons
                     } else {
                         for (uint32_t i = 0; i < len; i++) dst[i] = dst[(int)i - (int)dist];   // a short period in the first bytes of a block
                     }
+                    if constexpr (STAMP) st->v[6] += plen ? 0u : 1u;
                     pos += len;
                 }
+                if constexpr (STAMP) st->v[2] += __builtin_amdgcn_s_memtime() - ts2;
             }
             } else {
             for (;;) {
@@ -701,13 +768,16 @@ __device__ uint32_t inflate_block(const uint8_t *comp, uint64_t comp_bytes, cons
 }
 
 // grid of single-wave workgroups, each wave takes 64 consecutive blocks at a time
-template <bool DEFER>
+template <bool DEFER, bool PIECES = false, bool STAMP = false>
 __global__ void __launch_bounds__(INF_WAVE) bgzf_inflate_kernel(const uint8_t *comp, uint64_t comp_bytes, BgzfBlock *blocks,
-                                                                uint32_t n_blocks, uint8_t *out, uint32_t lit_run) {
+                                                                uint32_t n_blocks, uint8_t *out, uint32_t lit_run, unsigned long long *dbg = nullptr) {
     extern __shared__ __attribute__((aligned(16))) uint8_t inf_lds[];
     const uint32_t lane = threadIdx.x;
     const LaneLds t{inf_lds + 4u * lane, inf_lds + INF_N16 * 2 * INF_WAVE + 4u * lane,
                     (uint32_t *)(inf_lds + (INF_N16 * 2 + INF_N8) * INF_WAVE) + lane};
+    StepStamps stamps{};
+    uint64_t t_kernel0 = 0;
+    if constexpr (STAMP) t_kernel0 = __builtin_amdgcn_s_memtime();
     for (uint32_t g = blockIdx.x; g * INF_WAVE < n_blocks; g += gridDim.x) {
         const uint32_t i = g * INF_WAVE + lane;
         if (i < n_blocks) {
@@ -715,9 +785,14 @@ __global__ void __launch_bounds__(INF_WAVE) bgzf_inflate_kernel(const uint8_t *c
             uint32_t st = INF_OK;
             // (a descriptor the caller got wrong must not become a wild address)
             if (b.isize > 65536u || b.in_off > comp_bytes || b.in_len > comp_bytes - b.in_off) st = INF_BAD_BLOCK;
-            else if (b.isize) st = inflate_block<DEFER>(comp, comp_bytes, b, out, t, inf_lds + INF_LDS_BYTES, lane, min(max(lit_run, 1u), INF_RUN_DEFER_MAX));
+            else if (b.isize) st = inflate_block<DEFER, PIECES, STAMP>(comp, comp_bytes, b, out, t, inf_lds + INF_LDS_BYTES, lane, min(max(lit_run, 1u), INF_RUN_DEFER_MAX), &stamps);
             blocks[i].status = st;
         }
+    }
+    if constexpr (STAMP) {   // lane sums; [7] = lane-cycles inside the kernel (every lane counts the wave's whole life)
+        stamps.v[7] = __builtin_amdgcn_s_memtime() - t_kernel0;
+        if (dbg)
+            for (int k = 0; k < 8; k++) atomicAdd(&dbg[k], (unsigned long long)stamps.v[k]);
     }
 }
 

@@ -230,14 +230,17 @@ static int same_config(const pssbam_config *a, const pssbam_config *b)
  * or HIP call exists; the process the caller started only waits for one byte -- the exit status, sent when the
  * tables are written -- and returns it at once, while the child is dismantled in the background.  A child that
  * ends without sending it (a diagnosed exit(1), a signal) is waited for and its status / signal relayed.
- * PSSBAM_DETACH_EXIT=0 keeps everything in one process (the default under LD_PRELOAD: profilers and sanitizers
- * bring the GPU runtime up before main, and a fork behind that is not safe). */
+ * PSSBAM_DETACH_EXIT=0 keeps everything in one process (the default when LD_PRELOAD names a ROCm profiler: it
+ * brings the GPU runtime up before main, and a fork behind that is not safe). */
 static int detach_fd = -1;
 
 void frontend_detach_start(void)
 {
     const char *v = getenv("PSSBAM_DETACH_EXIT"), *pre = getenv("LD_PRELOAD");
-    if (v ? atoi(v) == 0 : (pre && *pre)) return;
+    /* (profilers live in LD_PRELOAD and bring the GPU runtime up before main: no fork behind them) */
+    const int tooling = pre && (strstr(pre, "rocprof") || strstr(pre, "roctracer") || strstr(pre, "roctx") || strstr(pre, "omnitrace") ||
+                                strstr(pre, "rocsys"));
+    if (v ? atoi(v) == 0 : tooling) return;
     int fds[2];
     if (pipe(fds) != 0) return;
     fflush(NULL);
@@ -267,6 +270,8 @@ void frontend_detach_start(void)
     }
     _exit(WIFEXITED(ws) ? WEXITSTATUS(ws) : 1);
 }
+
+int frontend_detached(void) { return detach_fd >= 0; }
 
 void front_end_exit(int status)
 {

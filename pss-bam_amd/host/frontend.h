@@ -38,6 +38,7 @@ void frontend_warmup_start(const pssbam_config *cfg, const char *aln_path, const
  * started returns the worker's exit status as soon as front_end_exit() sends it, without waiting for the worker's
  * teardown (frontend.c; PSSBAM_DETACH_EXIT=0 or a non-empty LD_PRELOAD: no fork). */
 void frontend_detach_start(void);
+int frontend_detached(void); /* 1 in a worker whose caller will be released by front_end_exit() */
 
 extern int frontend_fast_exit;
 void front_end_exit(int status);

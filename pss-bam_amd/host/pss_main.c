@@ -133,8 +133,8 @@ int main(int argc, char *argv[])
                     ? "  (more than 1 % of the records were longer than the staged prefix and took the one-lane path: slower, same tables)" : "");
         fprintf(stderr, "[pssbam] gpus=%d inflate_s=%.3f total_s=%.3f\n", res.n_gpus, res.inflate_s, res.total_s);
         fprintf(stderr, "[pssbam] main() to reports written: %.3f s\n", frontend_now_s() - t_main);
-        fprintf(stderr, "[pssbam] process creation to main(): %.2f s (exec + dynamic loading); main() to here %.3f s\n", age_main,
-                frontend_now_s() - t_main);
+        fprintf(stderr, "[pssbam] process creation to main(): %.2f s (exec + dynamic loading); main() to here %.3f s; exit: %s\n", age_main,
+                frontend_now_s() - t_main, frontend_detached() ? "the caller is released now, this worker is torn down behind it" : "one process, teardown in the foreground");
     }
     if (frontend_fast_exit) { /* nothing left to do but to hand the memory back: let the OS */
         fprintf(stderr, "Done.\n");

@@ -16,10 +16,12 @@ pytestmark = pytest.mark.gpu
 GOLD = Path(__file__).resolve().parent / "golden"
 
 
-@pytest.fixture(params=["in-place", "one-wait-per-step"], autouse=True)
+@pytest.fixture(params=["in-place", "one-wait-per-step", "one-wait-whole-copies"], autouse=True)
 def inflate_loop(request, monkeypatch):
-    """every test of this module runs under both data loops of the inflate kernel (csrc/inflate_kernels.h)"""
+    """every test of this module runs under the data loops of the inflate kernel (csrc/inflate_kernels.h): in place, one wait
+    per step with copies moved in pieces of <= 64 bytes (the feed's default), and one wait per step with whole copies"""
     monkeypatch.setenv("PSSBAM_INFLATE_LOOP", "0" if request.param == "in-place" else "1")
+    monkeypatch.setenv("PSSBAM_INFLATE_PIECES", "0" if request.param == "one-wait-whole-copies" else "1")
 
 
 @pytest.fixture(scope="module")

@@ -53,6 +53,7 @@ for st in settings:
         env[k] = v
     best = None
     for rep in range(2):
+        time.sleep(float(os.environ.get("SCAN_GAP_S", "1.0")))   # the previous run's worker / teardown is out of the way
         t = time.perf_counter()
         pr = subprocess.run([str(pkg.PKG_DIR / "bin" / "pss-bam"), "-F", str(fa), "-B", str(bam), "-o", str(tmp / "o"), "-r", str(region_len)],
                             capture_output=True, text=True, env=env)
