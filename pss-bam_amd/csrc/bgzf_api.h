@@ -2,6 +2,7 @@
 #pragma once
 
 #include "inflate_kernels.h"
+#include "inflate_wave.h"
 
 // walks BGZF block headers (SAM spec 4.1) over whole blocks; returns the count, or < 0
 extern "C" int64_t pssbam_bgzf_scan(const void *bytes, uint64_t nbytes, pssbam_bgzf_block *blocks, uint64_t max_blocks,
@@ -78,8 +79,19 @@ constexpr int INFLATE_LOOP_DEFAULT = 1;   // what the feed and the host convenie
 // (except for -2 = the public entry point, which is always 0).  The second loop requests up to 24 bytes past a block's end in d_out and re-reads the
 // last 16 bytes of d_comp: callers that ask for it own buffers with that slack.
 // out_bytes: what the batch inflates to (0 = unknown) -- picks the literal budget of the second loop.
+// what the wave-per-block path needs beside the block table (csrc/inflate_wave.h): the sequence arena, every block's
+// first entry in it (prefix sums of seq_cap_of(isize), worked out on the host) and a count per block
+struct WaveBufs { uint32_t *seq_arena; const uint64_t *seq_off; uint32_t *seq_count; };
+// OFF unless asked for (PSSBAM_INFLATE_WAVE=1; 2 = without the second chance for blocks it hands back): measured slower
+// than the lane-per-block kernel on every stream so far (profiles/r03_inflate_wave.txt) -- kept as the experiment it is,
+// behind pssbam_bgzf_inflate_host only, bit-exact against zlib in tests/test_gpu_inflate.py
+static bool wave_inflate_wanted() {
+    const char *v = getenv("PSSBAM_INFLATE_WAVE");
+    return v ? atoi(v) != 0 : false;
+}
+
 static int launch_inflate(hipStream_t st, const void *d_comp, uint64_t comp_bytes, pssbam_bgzf_block *d_blocks, uint32_t n_blocks,
-                          void *d_out, int check_crc, int loop, uint64_t out_bytes) {
+                          void *d_out, int check_crc, int loop, uint64_t out_bytes, const WaveBufs *wb = nullptr) {
     if (!n_blocks) return PSSBAM_OK;
     if (!d_comp || !d_blocks || !d_out) return fail(PSSBAM_EINVAL, "null buffer");
     if ((uintptr_t)d_comp & 3u) return fail(PSSBAM_EINVAL, "d_comp must be 4-byte aligned");
@@ -108,6 +120,38 @@ static int launch_inflate(hipStream_t st, const void *d_comp, uint64_t comp_byte
     if (const char *lr = getenv("PSSBAM_INFLATE_RUN")) lit_run = (uint32_t)std::max(1, atoi(lr));
     const char *pv = getenv("PSSBAM_INFLATE_PIECES");
     const bool pieces = pv ? atoi(pv) != 0 : true;   // bounded work per lane and step (csrc/inflate_kernels.h INF_PIECE)
+    uint32_t only_status = 0xFFFFFFFFu;
+    if (wb && loop > 0 && pieces && wave_inflate_wanted() && !getenv("PSSBAM_INFLATE_STAMPS")) {
+        // one wave per block: Huffman decoding into sequences + literals, then LZ77 in a 64 KiB LDS window per block; the
+        // lane-per-block kernel below only takes the blocks that path hands back (INF_RETRY)
+        const char *wg = getenv("PSSBAM_WAVE_WGS_PER_CU");
+        const uint32_t tgrid = std::min<uint32_t>((n_blocks + pssbam::WV_WAVES - 1) / pssbam::WV_WAVES, (uint32_t)n_cu * (wg && atoi(wg) > 0 ? (uint32_t)atoi(wg) : 12u));   // (13 KiB of LDS per one-wave workgroup: twelve per CU)
+        unsigned long long *d_wdbg = nullptr;
+        if (getenv("PSSBAM_WAVE_STAMPS")) {   // diagnostics: where the token kernel's cycles go
+            static unsigned long long *d_dbg2 = nullptr;
+            if (!d_dbg2) HIP_TRY(hipMalloc(&d_dbg2, 20 * sizeof(unsigned long long)));
+            HIP_TRY(hipMemsetAsync(d_dbg2, 0, 20 * sizeof(unsigned long long), st));
+            d_wdbg = d_dbg2;
+        }
+        hipLaunchKernelGGL(pssbam::bgzf_tokens_kernel, dim3(tgrid), dim3(64 * pssbam::WV_WAVES), 0, st, (const uint8_t *)d_comp, comp_bytes, (pssbam::BgzfBlock *)d_blocks,
+                           n_blocks, (uint8_t *)d_out, wb->seq_arena, wb->seq_off, wb->seq_count, d_wdbg);
+        const char *rg = getenv("PSSBAM_RESOLVE_WGS_PER_CU");
+        const uint32_t rgrid = std::min<uint32_t>((n_blocks + pssbam::RS_WAVES - 1) / pssbam::RS_WAVES, (uint32_t)n_cu * (rg && atoi(rg) > 0 ? (uint32_t)atoi(rg) : 4u));
+        hipLaunchKernelGGL(pssbam::bgzf_resolve_kernel, dim3(rgrid), dim3(64 * pssbam::RS_WAVES), 0, st, (uint8_t *)d_out, (pssbam::BgzfBlock *)d_blocks, n_blocks,
+                           (const uint32_t *)wb->seq_arena, wb->seq_off, (const uint32_t *)wb->seq_count, d_wdbg);
+        HIP_TRY(hipGetLastError());
+        if (d_wdbg) {
+            unsigned long long h[20];
+            HIP_TRY(hipMemcpyAsync(h, d_wdbg, sizeof h, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            const double nb = (double)std::max<unsigned long long>(h[9], 1), rb = (double)std::max<unsigned long long>(h[16], 1);
+            fprintf(stderr, "[pssbam] token kernel stamps, shader cycles per BGZF block (%.0f blocks, %.2f chunks each): set-up+stored %.0f, code-length walk %.0f, table builds %.0f, "
+                            "walk A1 %.0f, A2 %.0f, path %.0f, B+scans %.0f, C %.0f\n", nb, h[8] / nb, h[0] / nb, h[1] / nb, h[2] / nb, h[3] / nb, h[4] / nb, h[5] / nb, h[6] / nb, h[7] / nb);
+            fprintf(stderr, "[pssbam] resolve kernel stamps, shader cycles per BGZF block (%.0f blocks, %.1f batches and %.1f rounds each): window in %.0f, scans %.0f, rounds %.0f, window out %.0f\n",
+                    rb, h[14] / rb, h[15] / rb, h[10] / rb, h[11] / rb, h[12] / rb, h[13] / rb);
+        }
+        only_status = pssbam::INF_RETRY;
+    }
     if (loop > 0 && getenv("PSSBAM_INFLATE_STAMPS")) {   // diagnostic build: where the cycles of a step go (tools/inflate_stamps.sh)
         static unsigned long long *d_dbg = nullptr;
         if (!d_dbg) HIP_TRY(hipMalloc(&d_dbg, 8 * sizeof(unsigned long long)));
@@ -125,9 +169,11 @@ static int launch_inflate(hipStream_t st, const void *d_comp, uint64_t comp_byte
         fprintf(stderr, "[pssbam] inflate stamps (pieces %d; lane sums, shader cycles): steps %llu, per step: decode %.0f wait %.0f stores+copies %.0f cycles; lanes in a step %.1f of 64; "
                         "literals per step %.2f; steps ending in an in-place copy %.3f; in-loop share of the lanes' kernel cycles %.3f\n", (int)pieces,
                 h[3], h[0] / L, h[1] / L, h[2] / L, h[4] / L, h[5] / L, h[6] / L, (double)(h[0] + h[1] + h[2]) / (double)std::max<unsigned long long>(h[7], 1));
+    } else if (only_status != 0xFFFFFFFFu && getenv("PSSBAM_INFLATE_WAVE") && atoi(getenv("PSSBAM_INFLATE_WAVE")) == 2) {
+        // (diagnostics: no second chance -- a block the wave path handed back stays in state INF_RETRY and is reported)
     } else if (loop > 0 && pieces)
         hipLaunchKernelGGL((pssbam::bgzf_inflate_kernel<true, true>), dim3(grid), dim3(pssbam::INF_WAVE), pssbam::INF_LDS_BYTES_DEFER, st, (const uint8_t *)d_comp,
-                           comp_bytes, (pssbam::BgzfBlock *)d_blocks, n_blocks, (uint8_t *)d_out, lit_run);
+                           comp_bytes, (pssbam::BgzfBlock *)d_blocks, n_blocks, (uint8_t *)d_out, lit_run, (unsigned long long *)nullptr, only_status);
     else if (loop > 0)
         hipLaunchKernelGGL(pssbam::bgzf_inflate_kernel<true>, dim3(grid), dim3(pssbam::INF_WAVE), pssbam::INF_LDS_BYTES_DEFER, st, (const uint8_t *)d_comp,
                            comp_bytes, (pssbam::BgzfBlock *)d_blocks, n_blocks, (uint8_t *)d_out, lit_run);
@@ -178,20 +224,32 @@ extern "C" int pssbam_bgzf_inflate_host(int device, const void *bgzf, uint64_t n
     if (device >= 0) HIP_TRY(hipSetDevice(device));
     uint8_t *d_comp = nullptr, *d_out = nullptr;
     pssbam_bgzf_block *d_blocks = nullptr;
+    uint32_t *d_seq = nullptr, *d_seq_count = nullptr;
+    uint64_t *d_seq_off = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     int rc = PSSBAM_OK;
     auto cleanup = [&]() {
         if (d_comp) (void)hipFree(d_comp);
         if (d_out) (void)hipFree(d_out);
         if (d_blocks) (void)hipFree(d_blocks);
+        if (d_seq) (void)hipFree(d_seq);
+        if (d_seq_off) (void)hipFree(d_seq_off);
+        if (d_seq_count) (void)hipFree(d_seq_count);
         if (e0) (void)hipEventDestroy(e0);
         if (e1) (void)hipEventDestroy(e1);
     };
 #define TRY_C(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { cleanup(); return fail(PSSBAM_EHIP, "%s failed: %s", #expr, hipGetErrorString(_e)); } } while (0)
-    TRY_C(hipMalloc(&d_comp, nbytes + 16));
+    TRY_C(hipMalloc(&d_comp, nbytes + 64));
+    std::vector<uint64_t> seq_off((size_t)n + 1, 0);
+    for (int64_t i = 0; i < n; i++) seq_off[(size_t)i + 1] = seq_off[(size_t)i] + pssbam::seq_cap_of(blocks[(size_t)i].isize);
+    TRY_C(hipMalloc(&d_seq, (seq_off[(size_t)n] + 64) * sizeof(uint32_t)));
+    TRY_C(hipMalloc(&d_seq_off, ((size_t)n + 1) * sizeof(uint64_t)));
+    TRY_C(hipMalloc(&d_seq_count, (size_t)n * sizeof(uint32_t)));
+    TRY_C(hipMemcpy(d_seq_off, seq_off.data(), ((size_t)n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
+    const WaveBufs wbufs{d_seq, d_seq_off, d_seq_count};
     TRY_C(hipMalloc(&d_out, total + 128));   // (slack for the one-wait-per-step loop's requests: up to 64 bytes past a block's end)
     TRY_C(hipMalloc(&d_blocks, (size_t)n * sizeof(pssbam_bgzf_block)));
-    TRY_C(hipMemset(d_comp + nbytes, 0, 16));
+    TRY_C(hipMemset(d_comp + nbytes, 0, 64));
     TRY_C(hipMemcpy(d_comp, bgzf, nbytes, hipMemcpyHostToDevice));
     TRY_C(hipMemcpy(d_blocks, blocks.data(), (size_t)n * sizeof(pssbam_bgzf_block), hipMemcpyHostToDevice));
     TRY_C(hipEventCreate(&e0));
@@ -200,7 +258,7 @@ extern "C" int pssbam_bgzf_inflate_host(int device, const void *bgzf, uint64_t n
     float best = 1e30f;
     for (int r = 0; r < repeats && rc == PSSBAM_OK; r++) {
         TRY_C(hipEventRecord(e0, nullptr));
-        rc = launch_inflate(nullptr, d_comp, nbytes, d_blocks, (uint32_t)n, d_out, check_crc, INFLATE_LOOP_DEFAULT, total);
+        rc = launch_inflate(nullptr, d_comp, nbytes, d_blocks, (uint32_t)n, d_out, check_crc, INFLATE_LOOP_DEFAULT, total, &wbufs);
         if (rc) break;
         TRY_C(hipEventRecord(e1, nullptr));
         TRY_C(hipEventSynchronize(e1));

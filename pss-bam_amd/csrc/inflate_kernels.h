@@ -770,7 +770,8 @@ __device__ uint32_t inflate_block(const uint8_t *comp, uint64_t comp_bytes, cons
 // grid of single-wave workgroups, each wave takes 64 consecutive blocks at a time
 template <bool DEFER, bool PIECES = false, bool STAMP = false>
 __global__ void __launch_bounds__(INF_WAVE) bgzf_inflate_kernel(const uint8_t *comp, uint64_t comp_bytes, BgzfBlock *blocks,
-                                                                uint32_t n_blocks, uint8_t *out, uint32_t lit_run, unsigned long long *dbg = nullptr) {
+                                                                uint32_t n_blocks, uint8_t *out, uint32_t lit_run, unsigned long long *dbg = nullptr,
+                                                                uint32_t only_status = 0xFFFFFFFFu /* != ~0: only the blocks left in that state */) {
     extern __shared__ __attribute__((aligned(16))) uint8_t inf_lds[];
     const uint32_t lane = threadIdx.x;
     const LaneLds t{inf_lds + 4u * lane, inf_lds + INF_N16 * 2 * INF_WAVE + 4u * lane,
@@ -782,6 +783,7 @@ __global__ void __launch_bounds__(INF_WAVE) bgzf_inflate_kernel(const uint8_t *c
         const uint32_t i = g * INF_WAVE + lane;
         if (i < n_blocks) {
             const BgzfBlock b = blocks[i];
+            if (only_status != 0xFFFFFFFFu && b.status != only_status) continue;
             uint32_t st = INF_OK;
             // (a descriptor the caller got wrong must not become a wild address)
             if (b.isize > 65536u || b.in_off > comp_bytes || b.in_len > comp_bytes - b.in_off) st = INF_BAD_BLOCK;

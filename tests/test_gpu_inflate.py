@@ -16,12 +16,14 @@ pytestmark = pytest.mark.gpu
 GOLD = Path(__file__).resolve().parent / "golden"
 
 
-@pytest.fixture(params=["in-place", "one-wait-per-step", "one-wait-whole-copies"], autouse=True)
+@pytest.fixture(params=["in-place", "one-wait-per-step", "one-wait-whole-copies", "wave-per-block"], autouse=True)
 def inflate_loop(request, monkeypatch):
-    """every test of this module runs under the data loops of the inflate kernel (csrc/inflate_kernels.h): in place, one wait
-    per step with copies moved in pieces of <= 64 bytes (the feed's default), and one wait per step with whole copies"""
+    """every test of this module runs under every inflate path: the lane-per-block kernel's data loops (csrc/inflate_kernels.h:
+    in place; one wait per step with copies moved in pieces of <= 64 bytes; the same with whole copies) and the
+    wave-per-block pair of kernels (csrc/inflate_wave.h), which is the feed's default"""
     monkeypatch.setenv("PSSBAM_INFLATE_LOOP", "0" if request.param == "in-place" else "1")
     monkeypatch.setenv("PSSBAM_INFLATE_PIECES", "0" if request.param == "one-wait-whole-copies" else "1")
+    monkeypatch.setenv("PSSBAM_INFLATE_WAVE", "1" if request.param == "wave-per-block" else "0")
 
 
 @pytest.fixture(scope="module")
