@@ -585,13 +585,40 @@ __device__ uint32_t inflate_block(const uint8_t *comp, uint64_t comp_bytes, cons
                     st->v[5] += run;
                 }
                 if (plen) {
-                    const uint4 pa = *(const uint4 *)(land + 16u * lane);
-                    if (pdist) store_run(pdst, ((uint64_t)pa.z | ((uint64_t)pa.w << 32)) >> (8u * (8u - pdist)), pdist, plen);
-                    else if constexpr (PIECES) {
-                        const uint4 pb = *(const uint4 *)(land + 16u * INF_WAVE + 16u * lane), pc = *(const uint4 *)(land + 32u * INF_WAVE + 16u * lane),
-                                    pd = *(const uint4 *)(land + 48u * INF_WAVE + 16u * lane);
-                        store_piece(pdst, pa, pb, pc, pd, plen);
-                    } else if (plen > 16u) {
+                    uint4 pa = *(const uint4 *)(land + 16u * lane);
+                    if constexpr (PIECES) {
+                        // ONE store path for far pieces and for runs of period 1, 2, 4 (the QUAL runs: their 16-byte pattern stands
+                        // in for all four planes) -- with 64 lanes SOME lane has each kind at nearly every step, and a wave pays
+                        // for every path any of its lanes takes.  Whole 16-byte groups: the <= 15 bytes behind a piece's end are
+                        // positions this lane fills LATER in program order (this step's literals, the next piece, the next token),
+                        // and one lane's stores to one address keep their order; only at the block's end the exact form is used.
+                        uint4 pb = *(const uint4 *)(land + 16u * INF_WAVE + 16u * lane), pc = *(const uint4 *)(land + 32u * INF_WAVE + 16u * lane),
+                              pd = *(const uint4 *)(land + 48u * INF_WAVE + 16u * lane);
+                        bool common = true;
+                        if (pdist) {
+                            uint64_t pat = (((uint64_t)pa.z | ((uint64_t)pa.w << 32)) >> (8u * (8u - pdist))) & ((1ull << (8u * pdist)) - 1ull);
+                            if ((8u % pdist) == 0u) {
+                                pat |= pdist < 2u ? pat << 8 : 0ull;
+                                pat |= pdist < 4u ? pat << 16 : 0ull;
+                                pat |= pat << 32;
+                                pa.x = pa.z = (uint32_t)pat;
+                                pa.y = pa.w = (uint32_t)(pat >> 32);
+                                pb = pc = pd = pa;
+                            } else {
+                                store_run(pdst, pat, pdist, plen);   // (periods 3, 5, 6, 7: rare)
+                                common = false;
+                            }
+                        }
+                        if (common) {
+                            if ((uint32_t)(pdst - out) + ((plen + 15u) & ~15u) <= isize) {
+                                store_u128(pdst, pa);
+                                if (plen > 16u) store_u128(pdst + 16, pb);
+                                if (plen > 32u) store_u128(pdst + 32, pc);
+                                if (plen > 48u) store_u128(pdst + 48, pd);
+                            } else store_piece(pdst, pa, pb, pc, pd, plen);
+                        }
+                    } else if (pdist) store_run(pdst, ((uint64_t)pa.z | ((uint64_t)pa.w << 32)) >> (8u * (8u - pdist)), pdist, plen);
+                    else if (plen > 16u) {
                         const uint4 pb = *(const uint4 *)(land + 16u * INF_WAVE + 16u * lane);
                         store_u128(pdst, pa);
                         store_tail16(pdst + 16, (uint64_t)pb.x | ((uint64_t)pb.y << 32), (uint64_t)pb.z | ((uint64_t)pb.w << 32), plen - 16u);
@@ -609,7 +636,8 @@ __device__ uint32_t inflate_block(const uint8_t *comp, uint64_t comp_bytes, cons
                 br.take_group(*(const uint4 *)(land + STREAM_PLANE + 16u * lane));
                 if (run) {
                     if (run > isize - pos) return INF_OVERRUN;
-                    store_tail(out + pos, lits, run);
+                    if (PIECES && pos + 8u <= isize) store_u64(out + pos, lits);   // (the bytes behind the literals: filled later, as above)
+                    else store_tail(out + pos, lits, run);
                     pos += run;
                 }
                 if (sym == 256) {
