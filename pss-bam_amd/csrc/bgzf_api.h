@@ -607,6 +607,8 @@ static int feed_flush(pssbam_engine *e) {
                        e->d_carry, (uint64_t)FEED_GAP, e->d_feed_tail, e->d_feed_flags);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev1, e->stream));
+    if (!s.inflated) HIP_TRY(hipEventCreateWithFlags(&s.inflated, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(s.inflated, e->stream));
     e->inflate_events.emplace_back(ev0, ev1);
     e->inflated_bytes += data_end - FEED_GAP;
     // the tally: now, or -- inflated ahead of the genome -- when set_references comes
@@ -723,6 +725,7 @@ extern "C" int pssbam_engine_submit_bgzf(pssbam_engine *e, const void *comp, uin
         HIP_TRY(hipMemsetAsync(e->d_feed_flags, 0, sizeof(uint32_t), e->stream));
         HIP_TRY(hipMalloc(&e->d_feed_tail, sizeof(uint64_t)));
         HIP_TRY(hipMemsetAsync(e->d_feed_tail, 0, sizeof(uint64_t), e->stream));
+        if (const char *ib = getenv("PSSBAM_FEED_IDLE_BLOCKS")) e->feed_idle_min_blocks = atoi(ib) > 0 ? (uint64_t)atoi(ib) : ~0ull;
     }
     // All or nothing: while the tallies are put off a slot may be unobtainable (PSSBAM_EBUSY) -- find that out before
     // the first block of this chunk is taken.  A chunk spills over into at most one more super-batch (<= 1 GiB against
@@ -776,7 +779,18 @@ extern "C" int pssbam_engine_submit_bgzf(pssbam_engine *e, const void *comp, uin
         rc = feed_append(e, (const uint8_t *)comp, blocks, b0, b1, cs);
         if (rc) return rc;
         b0 = b1;
-        if (cur.blocks.size() >= block_target || cur.out_used - FEED_GAP >= byte_target) {
+        bool flush_now = cur.blocks.size() >= block_target || cur.out_used - FEED_GAP >= byte_target;
+        if (!flush_now && cur.blocks.size() >= e->feed_idle_min_blocks && e->flush_seq > 0) {
+            // The device has run dry (everything flushed so far has been inflated) while this super-batch is still being
+            // collected -- the loaders are the slower side, typically while the caller's FASTA parser has the CPUs: a partial
+            // round now (the lanes without a block idle) beats a full one later
+            const FeedAcc *last = nullptr;
+            for (const FeedAcc *sp : e->feed)
+                if (sp->busy && sp->flush_seq == e->flush_seq) last = sp;
+            if (last && hipEventQuery(last->copies_done) == hipSuccess && hipEventQuery(last->inflated) == hipSuccess) { flush_now = true; e->feed_early_flushes++; }
+            (void)hipGetLastError();
+        }
+        if (flush_now) {
             rc = feed_flush(e);
             if (rc) return rc;
         }
@@ -848,9 +862,9 @@ extern "C" int pssbam_engine_feed_status(pssbam_engine *e, uint32_t *flags, doub
     }
     e->inflate_events.clear();
     if (getenv("PSSBAM_STATS"))
-        fprintf(stderr, "[pssbam] engine feed: %llu super-batches in %zu slots (%llu allocated here), %llu tally launches put off until the genome was set; "
+        fprintf(stderr, "[pssbam] engine feed: %llu super-batches (%llu cut short because the device had run dry) in %zu slots (%llu allocated here), %llu tally launches put off until the genome was set; "
                         "buffer allocation %.3f, waiting for a busy slot %.3f, flush (block table + launches) %.3f s\n",
-                (unsigned long long)e->flush_seq, e->feed.size(), (unsigned long long)e->feed_slots_allocated, (unsigned long long)e->feed_deferred_launches,
+                (unsigned long long)e->flush_seq, (unsigned long long)e->feed_early_flushes, e->feed.size(), (unsigned long long)e->feed_slots_allocated, (unsigned long long)e->feed_deferred_launches,
                 e->feed_t_alloc, e->feed_t_wait_busy, e->feed_t_flush);
     if (flags) *flags = f;
     if (inflate_ms) *inflate_ms = e->inflate_ms;

@@ -110,7 +110,7 @@ struct FeedAcc {  // one super-batch of compressed blocks: assembled chunk by ch
     uint32_t *d_nrecs = nullptr;
     size_t nrecs_cap = 0;
     uint64_t *d_chain = nullptr;             // [0] where this super-batch's chain starts, [1] where its tail starts
-    hipEvent_t consumed = nullptr, copies_done = nullptr, copies_done2 = nullptr;
+    hipEvent_t consumed = nullptr, copies_done = nullptr, copies_done2 = nullptr, inflated = nullptr;
     bool busy = false;                       // flushed; its buffers are in use until `consumed`
     bool held = false;                       // ... and its tally launches still wait for the genome (no `consumed` yet)
     uint64_t flush_seq = 0;                  // order of the flushes (the oldest busy slot frees first)
@@ -172,6 +172,8 @@ struct pssbam_engine {
     int32_t star_contig = -1;
     // references
     uint4 *d_ref_info = nullptr;  // n_ref + 1 entries (last = RNAME "*")
+    uint4 *h_ref_info = nullptr;  // the same in page-locked host memory: a kernel copies it over (below)
+    size_t h_ref_cap = 0;
     int32_t n_ref = 0;
     bool have_refs = false;
     // -R
@@ -199,7 +201,8 @@ struct pssbam_engine {
     uint8_t *d_carry = nullptr;        // the partial record a super-batch ended with, on its way into the next slot's gap
     uint64_t feed_out_target = FEED_OUT_TARGET, feed_comp_cap = FEED_COMP_CAP;   // per super-batch
     double feed_t_alloc = 0, feed_t_wait_busy = 0, feed_t_flush = 0;   // host seconds inside the feed (PSSBAM_STATS)
-    uint64_t feed_slots_allocated = 0, feed_deferred_launches = 0;
+    uint64_t feed_slots_allocated = 0, feed_deferred_launches = 0, feed_early_flushes = 0;
+    uint64_t feed_idle_min_blocks = 8192;   // a super-batch of at least so many blocks is flushed early when the device has run dry ($PSSBAM_FEED_IDLE_BLOCKS, 0 = never)
     uint64_t feed_block_target = 0;   // blocks per super-batch: a whole number of rounds of the inflate kernel's lanes
     std::vector<std::pair<uint64_t, hipEvent_t>> feed_copies;             // (ticket, copy-complete event) of submits
     std::vector<hipEvent_t> feed_event_pool;
@@ -318,6 +321,11 @@ extern "C" int pssbam_engine_create(const pssbam_config *cfg, pssbam_engine **ou
         HIP_TRY(hipEventCreate(&s.copied));
         HIP_TRY(hipEventCreateWithFlags(&s.consumed, hipEventDisableTiming));
     }
+    // the tiled kernels' per-workgroup scratch, for the largest grid the launcher picks on its own (8 workgroups per CU): a
+    // first launch that had to allocate it would first wait for everything queued on the stream -- with the compressed feed
+    // running ahead of the genome that is tens of ms of inflate kernels (launch_tally)
+    e->scratch_slots = (size_t)e->n_cu * 8;
+    HIP_TRY(hipMalloc(&e->d_scratch, e->scratch_slots * SCRATCH_WORDS * sizeof(uint32_t)));
     e->env_tile_reads = env_int("PSSBAM_TILE_READS");
     e->env_grid_mult = env_int("PSSBAM_GRID_MULT");
     e->env_simple_blocks = env_int("PSSBAM_SIMPLE_BLOCKS");
@@ -353,6 +361,7 @@ extern "C" void pssbam_engine_destroy(pssbam_engine *e) {
         if (s.consumed) (void)hipEventDestroy(s.consumed);
         if (s.copies_done) (void)hipEventDestroy(s.copies_done);
         if (s.copies_done2) (void)hipEventDestroy(s.copies_done2);
+        if (s.inflated) (void)hipEventDestroy(s.inflated);
         delete sp;
     }
     e->feed.clear();
@@ -371,6 +380,7 @@ extern "C" void pssbam_engine_destroy(pssbam_engine *e) {
     if (e->d_genome) (void)hipFree(e->d_genome);
     if (e->d_genome4) (void)hipFree(e->d_genome4);
     if (e->d_ref_info) (void)hipFree(e->d_ref_info);
+    if (e->h_ref_info) (void)hipHostFree(e->h_ref_info);
     if (e->d_rg) (void)hipFree(e->d_rg);
     if (e->d_counters_own) (void)hipFree(e->d_counters_own);
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
@@ -565,7 +575,18 @@ extern "C" int pssbam_engine_set_references(pssbam_engine *e, int32_t n_ref, con
         e->d_ref_info = nullptr;
     }
     HIP_TRY(hipMalloc(&e->d_ref_info, ((size_t)n_ref + 1) * sizeof(uint4)));
-    HIP_TRY(hipMemcpy(e->d_ref_info, info.data(), ((size_t)n_ref + 1) * sizeof(uint4), hipMemcpyHostToDevice));
+    // The table is a few hundred bytes, but a hipMemcpy of it queues behind whatever the copy engines are moving -- the 3 GB
+    // genome, typically: 50 ms during which the calling thread feeds nothing.  It goes through page-locked host memory
+    // instead and a one-workgroup kernel on the engine's stream reads it from there (ordered in front of every tally).
+    if (e->h_ref_cap < (size_t)n_ref + 1) {
+        if (e->h_ref_info) (void)hipHostFree(e->h_ref_info);
+        e->h_ref_info = nullptr;
+        e->h_ref_cap = (size_t)n_ref + 1 + 64;
+        HIP_TRY(hipHostMalloc((void **)&e->h_ref_info, e->h_ref_cap * sizeof(uint4), hipHostMallocDefault));
+    } else if (e->have_refs) HIP_TRY(hipStreamSynchronize(e->stream));   // (a kernel may still be reading the previous contents)
+    memcpy(e->h_ref_info, info.data(), ((size_t)n_ref + 1) * sizeof(uint4));
+    hipLaunchKernelGGL(copy_table_kernel, dim3(1), dim3(256), 0, e->stream, e->d_ref_info, (const uint4 *)e->h_ref_info, (uint32_t)n_ref + 1u);
+    HIP_TRY(hipGetLastError());
     e->n_ref = n_ref;
     e->have_refs = true;
     return feed_resume(e);   // super-batches inflated ahead of the genome are tallied now

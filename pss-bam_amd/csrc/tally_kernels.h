@@ -1159,6 +1159,11 @@ __global__ void __launch_bounds__(512) genome_kmer_packed_kernel(const uint32_t 
 // Upload-time genome transform: toupper() fold (init_genome stores upper case,
 // fasta-genome-io.c:127; process_aln folds again, pss-bam.c:424) followed by the
 // A/C/G/T <-> 0..3 byte swap of record_decode.h.  16 bytes per lane per step.
+// a small table from page-locked host memory into device memory (engine.hip: the reference table)
+__global__ void copy_table_kernel(uint4 *dst, const uint4 *src, uint32_t n) {
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+}
+
 __global__ void encode_genome_kernel(uint8_t *p, uint64_t n16) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     uint4 *q = (uint4 *)p;

@@ -1,7 +1,7 @@
 # tools/e2e_prof.sh -- GPU-box helper: rocprofv3 kernel stats of the whole bin/pss-bam command on a generated BAM + FASTA
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/prof_e2e
-mkdir -p $OUT /tmp/e2e_in
+rm -rf $OUT/stats; mkdir -p $OUT /tmp/e2e_in
 python3 - <<'PY'
 import sys, os
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')

@@ -58,19 +58,14 @@ def spread(a, b, arr, weight=None):
 
 for a, b, g, _ in ker:
     spread(a, b, occ[g])
-for a, b, d, n in cp:
+for a, b, d, n in cp:   # (the trace has no byte counts: the share of the bin with a host-to-device copy in flight, copies summed)
     if "HOST_TO_DEVICE" in d.upper() or "H2D" in d.upper():
-        i, aa = int((a - t0) / binns), a
-        while aa < b and i < nb:
-            e = min(b, t0 + (i + 1) * binns)
-            h2d[i] += n * (e - aa) / max(b - a, 1)
-            aa = e
-            i += 1
+        spread(a, b, h2d)
 print(f"# {len(ker)} kernel dispatches, {len(cp)} copies; t = 0 at the first of them; bins of {args.bin:g} ms; "
-      f"columns = share of the bin with a kernel of that group running (streams overlap: shares can add up past 1), H2D GB/s")
-print("t_ms   " + "".join(f"{g:>9s}" for g in names) + "   h2d_GBps")
+      f"columns = share of the bin with a kernel of that group running / a host-to-device copy in flight (streams overlap: shares can add up past 1)")
+print("t_ms   " + "".join(f"{g:>9s}" for g in names) + "   h2d_copy")
 for i in range(nb):
-    print(f"{i * args.bin:6.0f} " + "".join(f"{occ[g][i] / binns:9.2f}" for g in names) + f"   {h2d[i] / (binns * 1e-9) / 1e9:8.1f}")
+    print(f"{i * args.bin:6.0f} " + "".join(f"{occ[g][i] / binns:9.2f}" for g in names) + f"   {h2d[i] / binns:8.2f}")
 # union of kernel intervals
 busy, cur_a, cur_b, gaps = 0, None, None, []
 for a, b, g, n in ker:
@@ -102,5 +97,5 @@ if gen and inf:
     print(f"# genome kernels ran from {(g_a - t0) / 1e6:.1f} to {(g_b - t0) / 1e6:.1f} ms; {before} inflate launches had STARTED before they ended, "
           f"{over / 1e6:.1f} ms of inflate ran beside them")
 if cp:
-    tot = sum(n for a, b, d, n in cp if "HOST_TO_DEVICE" in d.upper() or "H2D" in d.upper())
-    print(f"# host-to-device: {tot / 1e9:.2f} GB between {(min(c[0] for c in cp) - t0) / 1e6:.1f} and {(max(c[1] for c in cp) - t0) / 1e6:.1f} ms")
+    tot = sum(b - a for a, b, d, n in cp if "HOST_TO_DEVICE" in d.upper() or "H2D" in d.upper())
+    print(f"# host-to-device copies: {tot / 1e6:.1f} ms of copy time between {(min(c[0] for c in cp) - t0) / 1e6:.1f} and {(max(c[1] for c in cp) - t0) / 1e6:.1f} ms")
