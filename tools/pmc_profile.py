@@ -28,6 +28,8 @@ from collections import defaultdict
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+from bench import kernel_blobs  # noqa: E402
 tag = sys.argv[1]
 assert sys.argv[2] == "--"
 bench_args = sys.argv[3:] + ["--no-cpu-baseline", "--no-e2e"]
@@ -109,6 +111,7 @@ if f and w and "reads_per_launch" in summary:
         "write_size_kb_per_launch": write_kb, "tcc_miss_x128_bytes_per_read": miss * 128.0 / rpl if miss else None,
         "l2_hit_rate": hit / (hit + miss) if hit is not None and miss else None,
         "kernel": f[1], "command": " ".join(cmd), "date": summary["date"],
+        "kernel_blobs": kernel_blobs(),   # git blob ids of the kernel sources measured (bench.py: roofline.traffic_stale)
     }
 (out / "summary.json").write_text(json.dumps(summary, indent=1))
 print(json.dumps({k: summary.get(k) for k in ("tag", "reads_per_launch", "traffic_entry")}, indent=1))
