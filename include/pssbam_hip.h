@@ -270,6 +270,13 @@ int pssbam_engine_feed_open(pssbam_engine *e, int32_t n_ref, uint64_t genome_byt
  * run of a file): pending blocks are processed, a partial record left at this point raises
  * PSSBAM_FEED_TRUNCATED, and the next blocks start a new record chain at their first byte. */
 int pssbam_engine_feed_break(pssbam_engine *e);
+/* Several engines dealt alternating runs of ONE stream (one BAM over n GPUs): the blocks submitted to `to`
+ * from now on continue the stream where the blocks submitted to `from` so far end.  `from`'s pending blocks
+ * are processed; the partial record its run ends in (records cross BGZF blocks in files written by htsjdk)
+ * travels to `to` -- device to device through page-locked host memory, no host wait -- and is completed,
+ * indexed and tallied there, so the record chain is checked across engines as it is inside one.  The
+ * reference has no counterpart (one process, one `samtools view` pipe: pss-bam.c:148-162, 764-783). */
+int pssbam_engine_feed_handoff(pssbam_engine *from, pssbam_engine *to);
 #define PSSBAM_FEED_BAD_BLOCK 1u   /* a block failed inflate / ISIZE / CRC-32                         */
 #define PSSBAM_FEED_RAGGED 2u      /* the per-block record chains did not link up (or a record above 16 MiB):
                                       use the host reader for this file                               */

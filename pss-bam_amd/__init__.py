@@ -38,7 +38,7 @@ HIP_SYMBOLS = [
     "pssbam_reduce_counters", "pssbam_engine_genome_kmer_count", "pssbam_host_register", "pssbam_host_unregister", "pssbam_engine_timer_begin",
     "pssbam_engine_timer_end", "pssbam_engine_kernel_time", "pssbam_index_records", "pssbam_bgzf_scan",
     "pssbam_bgzf_inflate_device", "pssbam_bgzf_inflate_host", "pssbam_engine_submit_bgzf", "pssbam_engine_wait_bgzf_copied",
-    "pssbam_engine_feed_status", "pssbam_engine_feed_break", "pssbam_feed_reserve", "pssbam_engine_hint_records",
+    "pssbam_engine_feed_status", "pssbam_engine_feed_break", "pssbam_engine_feed_handoff", "pssbam_feed_reserve", "pssbam_engine_hint_records",
     "pssbam_engine_set_genome_async", "pssbam_engine_genome_wait", "pssbam_engine_feed_open", "pssbam_feed_release",
 ]
 EBUSY = -7
@@ -323,6 +323,11 @@ class Engine:
     def feed_break(self):
         self._L.pssbam_engine_feed_break.argtypes = [C.c_void_p]
         _chk(self._L.pssbam_engine_feed_break(self._h))
+
+    def feed_handoff(self, to: "Engine"):
+        """the blocks submitted to `to` from now on continue this engine's stream (include/pssbam_hip.h)"""
+        self._L.pssbam_engine_feed_handoff.argtypes = [C.c_void_p, C.c_void_p]
+        _chk(self._L.pssbam_engine_feed_handoff(self._h, to._h))
 
     def feed_status(self) -> dict:
         L = self._L

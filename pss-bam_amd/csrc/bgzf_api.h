@@ -418,8 +418,8 @@ static int feed_prepare(pssbam_engine *e, FeedAcc &s) {
         if (rc) return rc;
     }
     if (!s.d_chain) {
-        HIP_TRY(hipMalloc(&s.d_chain, 2 * sizeof(uint64_t)));
-        HIP_TRY(hipMemsetAsync(s.d_chain, 0, 2 * sizeof(uint64_t), e->stream));
+        HIP_TRY(hipMalloc(&s.d_chain, 4 * sizeof(uint64_t)));
+        HIP_TRY(hipMemsetAsync(s.d_chain, 0, 4 * sizeof(uint64_t), e->stream));
     }
     if (!s.consumed) HIP_TRY(hipEventCreateWithFlags(&s.consumed, hipEventDisableTiming));
     return PSSBAM_OK;
@@ -576,11 +576,21 @@ static int feed_flush(pssbam_engine *e) {
         const uint32_t n = (uint32_t)nb, grid = std::min<uint32_t>((n + 255u) / 256u, (uint32_t)e->n_cu * 8u);
         const pssbam::BgzfBlock *blk = (const pssbam::BgzfBlock *)s.d_blocks;
         hipLaunchKernelGGL(pssbam::bgzf_chain_spec, dim3(grid), dim3(256), 0, e->stream, (const uint8_t *)s.d_out, blk, n, data_end,
-                           (const uint64_t *)s.d_chain, n_ref, s.d_a, s.d_n, s.d_e, s.d_last, e->d_feed_flags);
+                           (const uint64_t *)s.d_chain, n_ref, s.d_a, s.d_n, s.d_e, s.d_last, e->d_feed_flags, s.d_chain + 2);
         hipLaunchKernelGGL(pssbam::bgzf_chain_suffix, dim3(1), dim3(1024), 0, e->stream, (const uint64_t *)s.d_a, n, s.d_nexta);
-        hipLaunchKernelGGL(pssbam::bgzf_chain_verify, dim3(grid), dim3(256), 0, e->stream, (const uint8_t *)s.d_out, (const uint32_t *)s.d_n, (const uint64_t *)s.d_e,
+        hipLaunchKernelGGL(pssbam::bgzf_chain_verify<false>, dim3(grid), dim3(256), 0, e->stream, (const uint8_t *)s.d_out, (const uint32_t *)s.d_n, (const uint64_t *)s.d_e,
                            (const uint64_t *)s.d_last, (const uint64_t *)s.d_nexta, n, data_end, (const uint64_t *)s.d_chain, s.d_counts,
-                           s.d_chain + 1, e->d_feed_flags);
+                           s.d_chain + 1, e->d_feed_flags, s.d_chain + 2);
+        // links that do not hold are repaired from the left (a serial walk over the blocks in doubt only); what was
+        // repaired is linked and checked again.  Without a broken link the three launches return at once.
+        const char *rv = getenv("PSSBAM_FEED_REPAIR");
+        const int repair = rv ? atoi(rv) : 1;
+        hipLaunchKernelGGL(pssbam::bgzf_chain_repair, dim3(1), dim3(64), 0, e->stream, (const uint8_t *)s.d_out, blk, n, data_end, (const uint64_t *)s.d_chain,
+                           n_ref, s.d_a, s.d_n, s.d_e, s.d_last, (const uint64_t *)s.d_nexta, e->d_feed_flags, s.d_chain + 2, repair);
+        hipLaunchKernelGGL(pssbam::bgzf_chain_suffix, dim3(1), dim3(1024), 0, e->stream, (const uint64_t *)s.d_a, n, s.d_nexta);
+        hipLaunchKernelGGL(pssbam::bgzf_chain_verify<true>, dim3(grid), dim3(256), 0, e->stream, (const uint8_t *)s.d_out, (const uint32_t *)s.d_n, (const uint64_t *)s.d_e,
+                           (const uint64_t *)s.d_last, (const uint64_t *)s.d_nexta, n, data_end, (const uint64_t *)s.d_chain, s.d_counts,
+                           s.d_chain + 1, e->d_feed_flags, s.d_chain + 2);
     }
     // offsets per tally sub-batch: the records STARTING in its blocks, relative to a 16-byte aligned base
     uint64_t offs_at = 0;
@@ -666,6 +676,24 @@ static int feed_append(pssbam_engine *e, const uint8_t *comp, const pssbam_bgzf_
     return PSSBAM_OK;
 }
 
+// the feed's per-engine device words and targets, made at the first use of the feed
+static int feed_state_init(pssbam_engine *e) {
+    if (e->d_feed_flags) return PSSBAM_OK;
+    if (getenv("PSSBAM_FEED_SUPER_BYTES")) e->feed_out_target = std::max<uint64_t>(1ull << 20, strtoull(getenv("PSSBAM_FEED_SUPER_BYTES"), nullptr, 10));
+    // the inflate kernel keeps INF_WAVES_PER_CU waves x 64 lanes per CU busy, a block per lane, and blocks take about the
+    // same time: a super-batch of a whole number of "rounds" of blocks wastes no partial round
+    const uint64_t lanes = (uint64_t)e->n_cu * (uint64_t)pssbam::INF_WAVES_PER_CU * 64ull;
+    const uint64_t rounds = std::max<uint64_t>(1, e->feed_out_target / (lanes * 65280ull));
+    e->feed_block_target = getenv("PSSBAM_FEED_SUPER_BYTES") && e->feed_out_target < lanes * 65280ull ? 0xFFFFFFFFull : rounds * lanes;
+    HIP_TRY(hipMalloc(&e->d_feed_flags, sizeof(uint32_t)));
+    HIP_TRY(hipMemsetAsync(e->d_feed_flags, 0, sizeof(uint32_t), e->stream));
+    HIP_TRY(hipMalloc(&e->d_feed_tail, sizeof(uint64_t)));
+    HIP_TRY(hipMemsetAsync(e->d_feed_tail, 0, sizeof(uint64_t), e->stream));
+    if (!e->d_carry) HIP_TRY(hipMalloc(&e->d_carry, FEED_GAP));
+    if (const char *ib = getenv("PSSBAM_FEED_IDLE_BLOCKS")) e->feed_idle_min_blocks = atoi(ib) > 0 ? (uint64_t)atoi(ib) : ~0ull;
+    return PSSBAM_OK;
+}
+
 // Declares that compressed blocks will be fed BEFORE the genome is set: n_ref = the reference count of the BAM
 // header (the record chain is judged with it).  submit_bgzf is then legal at once; inflate, CRC-32 and the record
 // index run as the blocks arrive, the tally launches follow when set_genome(_async) + set_references have been
@@ -714,19 +742,7 @@ extern "C" int pssbam_engine_submit_bgzf(pssbam_engine *e, const void *comp, uin
     if (first_record_offset) e->feed_skip = first_record_offset;
     if (comp_bytes > e->feed_comp_cap / 2) return fail(PSSBAM_EINVAL, "chunk of %llu compressed bytes is too large", (unsigned long long)comp_bytes);
     HIP_TRY(hipSetDevice(e->device));
-    if (!e->d_feed_flags) {
-        if (getenv("PSSBAM_FEED_SUPER_BYTES")) e->feed_out_target = std::max<uint64_t>(1ull << 20, strtoull(getenv("PSSBAM_FEED_SUPER_BYTES"), nullptr, 10));
-        // the inflate kernel keeps INF_WAVES_PER_CU waves x 64 lanes per CU busy, a block per lane, and blocks take about the
-        // same time: a super-batch of a whole number of "rounds" of blocks wastes no partial round
-        const uint64_t lanes = (uint64_t)e->n_cu * (uint64_t)pssbam::INF_WAVES_PER_CU * 64ull;
-        const uint64_t rounds = std::max<uint64_t>(1, e->feed_out_target / (lanes * 65280ull));
-        e->feed_block_target = getenv("PSSBAM_FEED_SUPER_BYTES") && e->feed_out_target < lanes * 65280ull ? 0xFFFFFFFFull : rounds * lanes;
-        HIP_TRY(hipMalloc(&e->d_feed_flags, sizeof(uint32_t)));
-        HIP_TRY(hipMemsetAsync(e->d_feed_flags, 0, sizeof(uint32_t), e->stream));
-        HIP_TRY(hipMalloc(&e->d_feed_tail, sizeof(uint64_t)));
-        HIP_TRY(hipMemsetAsync(e->d_feed_tail, 0, sizeof(uint64_t), e->stream));
-        if (const char *ib = getenv("PSSBAM_FEED_IDLE_BLOCKS")) e->feed_idle_min_blocks = atoi(ib) > 0 ? (uint64_t)atoi(ib) : ~0ull;
-    }
+    if ((rc = feed_state_init(e))) return rc;
     // All or nothing: while the tallies are put off a slot may be unobtainable (PSSBAM_EBUSY) -- find that out before
     // the first block of this chunk is taken.  A chunk spills over into at most one more super-batch (<= 1 GiB against
     // 4.3 GB); with tiny test super-batches it may need more, which then go past the budget rather than fail half-way.
@@ -820,6 +836,40 @@ extern "C" int pssbam_engine_feed_break(pssbam_engine *e) {
     }
     e->feed_fresh = true;
     e->feed_skip = 0;
+    return PSSBAM_OK;
+}
+
+// Several engines are dealt alternating runs of ONE stream (one BAM, n GPUs): the blocks submitted to `to` from now on
+// continue the stream where the blocks submitted to `from` so far end.  What `from` has pending is flushed; the partial
+// record its run ends with (records cross BGZF blocks in files written by htsjdk) travels to `to` -- a few hundred bytes
+// through page-locked host memory, device to device by two small kernels and an event, no host wait -- and is completed,
+// indexed and tallied there.  The record chain is thus checked across the engines exactly as inside one.
+extern "C" int pssbam_engine_feed_handoff(pssbam_engine *from, pssbam_engine *to) {
+    if (!from || !to) return fail(PSSBAM_EINVAL, "null engine");
+    if (from == to) return PSSBAM_OK;
+    if (to->cfg.kernel == PSSBAM_KERNEL_SIMPLE) return fail(PSSBAM_EINVAL, "device-indexed blocks need the tiled kernels");
+    if (to->cur_feed >= 0 && !to->feed[(size_t)to->cur_feed]->blocks.empty())
+        return fail(PSSBAM_ESTATE, "the receiving engine is in the middle of a run (hand its own run on, or break it, first)");
+    if (!from->d_feed_tail) return fail(PSSBAM_ESTATE, "the engine handing on has been fed nothing");
+    int rc;
+    HIP_TRY(hipSetDevice(to->device));
+    if ((rc = feed_state_init(to))) return rc;
+    if (!to->h_handoff) HIP_TRY(hipHostMalloc((void **)&to->h_handoff, 8 + FEED_GAP, hipHostMallocPortable));
+    HIP_TRY(hipSetDevice(from->device));
+    if ((rc = feed_flush(from))) return rc;
+    if (!from->handoff_ev) HIP_TRY(hipEventCreateWithFlags(&from->handoff_ev, hipEventDisableTiming));
+    hipLaunchKernelGGL(pssbam::bgzf_chain_handoff_out, dim3(1), dim3(256), 0, from->stream, (const uint8_t *)from->d_carry, from->d_feed_tail,
+                       to->h_handoff + 8, (uint64_t *)to->h_handoff);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(from->handoff_ev, from->stream));
+    from->feed_fresh = false;   // (its next run, if any, starts with what is handed to IT)
+    HIP_TRY(hipSetDevice(to->device));
+    HIP_TRY(hipStreamWaitEvent(to->stream, from->handoff_ev, 0));
+    hipLaunchKernelGGL(pssbam::bgzf_chain_handoff_in, dim3(1), dim3(256), 0, to->stream, (const uint8_t *)(to->h_handoff + 8), (const uint64_t *)to->h_handoff,
+                       to->d_carry, (uint64_t)FEED_GAP, to->d_feed_tail);
+    HIP_TRY(hipGetLastError());
+    to->feed_fresh = false;
+    to->feed_skip = 0;
     return PSSBAM_OK;
 }
 

@@ -109,7 +109,7 @@ struct FeedAcc {  // one super-batch of compressed blocks: assembled chunk by ch
     size_t offs_cap = 0;
     uint32_t *d_nrecs = nullptr;
     size_t nrecs_cap = 0;
-    uint64_t *d_chain = nullptr;             // [0] where this super-batch's chain starts, [1] where its tail starts
+    uint64_t *d_chain = nullptr;             // [0] where this super-batch's chain starts, [1] where its tail starts, [2] links broken, [3] links repaired
     hipEvent_t consumed = nullptr, copies_done = nullptr, copies_done2 = nullptr, inflated = nullptr;
     bool busy = false;                       // flushed; its buffers are in use until `consumed`
     bool held = false;                       // ... and its tally launches still wait for the genome (no `consumed` yet)
@@ -199,6 +199,8 @@ struct pssbam_engine {
     uint64_t feed_mem_budget = 0;      // device bytes the ring may take while tallies are deferred (0: not worked out yet)
     std::vector<DeferredTally> deferred;
     uint8_t *d_carry = nullptr;        // the partial record a super-batch ended with, on its way into the next slot's gap
+    uint8_t *h_handoff = nullptr;      // page-locked [8 + FEED_GAP]: the partial record ANOTHER engine's run ended with arrives here (feed_handoff)
+    hipEvent_t handoff_ev = nullptr;   // recorded on this engine's stream behind the hand-off of its own tail
     uint64_t feed_out_target = FEED_OUT_TARGET, feed_comp_cap = FEED_COMP_CAP;   // per super-batch
     double feed_t_alloc = 0, feed_t_wait_busy = 0, feed_t_flush = 0;   // host seconds inside the feed (PSSBAM_STATS)
     uint64_t feed_slots_allocated = 0, feed_deferred_launches = 0, feed_early_flushes = 0;
@@ -366,6 +368,8 @@ extern "C" void pssbam_engine_destroy(pssbam_engine *e) {
     }
     e->feed.clear();
     if (e->d_carry) (void)hipFree(e->d_carry);
+    if (e->h_handoff) (void)hipHostFree(e->h_handoff);
+    if (e->handoff_ev) (void)hipEventDestroy(e->handoff_ev);
     for (void *q : e->retired) (void)hipFree(q);
     if (e->d_feed_tail) (void)hipFree(e->d_feed_tail);
     for (auto &p : e->feed_copies) (void)hipEventDestroy(p.second);

@@ -234,6 +234,32 @@ __device__ __forceinline__ bool huff_finish(const LaneLds &t, int cnt_at, int de
     return ok;
 }
 
+// The fifteen left-aligned upper bounds of a 15-length code as eight pairs of u16 (slot 15 = 0x8000: never reached), and
+// the length of the code the next 15 stream bits begin with: 1 + the number of bounds they reach.  Compare-and-add through
+// the scalar registers costs v_cmp + two wait states + v_addc per bound (hipcc: "s_nop 1" behind every v_cmp whose mask the
+// next VALU instruction reads -- 150 cycles of a one-wave-per-SIMD kernel per symbol); here: eight packed 16-bit
+// subtractions (the sign of a half = "below this bound"; 0x8000 - c wraps to "below" as it must), the sixteen sign bytes
+// gathered four to a register, four popcounts -- 22 instructions, no scalar round trip.
+struct Upper2 { uint32_t p[8]; };
+__device__ __forceinline__ void pack_upper(const uint32_t (&upper)[15], Upper2 &u) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) u.p[j] = upper[2 * j] | ((2 * j + 1 < 15 ? upper[2 * j + 1 < 15 ? 2 * j + 1 : 0] : 0x8000u) << 16);
+}
+__device__ __forceinline__ uint32_t code_len15(uint32_t c15, const Upper2 &u) {
+    typedef short short2v __attribute__((ext_vector_type(2)));
+    const uint32_t cc = c15 | (c15 << 16);
+    uint32_t d[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const short2v x = __builtin_bit_cast(short2v, cc) - __builtin_bit_cast(short2v, u.p[j]);
+        d[j] = __builtin_bit_cast(uint32_t, x);
+    }
+    uint32_t n = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) n += (uint32_t)__builtin_popcount(__builtin_amdgcn_perm(d[2 * j + 1], d[2 * j], 0x07050301u) & 0x80808080u);
+    return 17u - n;
+}
+
 // symbol for the next code of the stream; < 0: the bits are no code of this table.
 // WIDE: the literal/length table (9-bit symbols); else a u8 table at sym_at (distance / code-length code)
 template <int MAXL, bool WIDE>
@@ -250,25 +276,35 @@ __device__ __forceinline__ int huff_decode(BitReader &br, const LaneLds &t, int 
     return WIDE ? (int)t.get_litlen(idx) : (int)t.sym8(sym_at + (int)idx);
 }
 
+template <bool WIDE>
+__device__ __forceinline__ int huff_decode15(BitReader &br, const LaneLds &t, int delta_at, int sym_at, int n_sym, const Upper2 &upper) {
+    const uint32_t c15 = br.peek15();
+    const uint32_t L = code_len15(c15, upper);
+    if (L > 15u) return -1;
+    const uint32_t idx = ((c15 >> (15u - L)) + t.at(delta_at + (int)L)) & 0xFFFFu;
+    if (idx >= (uint32_t)n_sym) return -1;
+    br.drop(L);
+    return WIDE ? (int)t.get_litlen(idx) : (int)t.sym8(sym_at + (int)idx);
+}
+
 // The next TWO literal/length symbols, nothing dropped: b is decoded from the bits behind a's code before a's table
 // reads have come back, so the two LDS round trips of a symbol (offset of its code length, then the symbol) are
 // shared by the pair -- literal runs are what a BAM's quality strings inflate from.  sym < 0: no code of the table.
 struct LitPair { int a, b; uint32_t la, lb; };
-__device__ __forceinline__ LitPair litlen_peek2(const BitReader &br, const LaneLds &t, const uint32_t (&upper)[15]) {
+__device__ __forceinline__ LitPair litlen_peek2(const BitReader &br, const LaneLds &t, const Upper2 &upper) {
     const uint32_t ca = br.peek15();
-    uint32_t la = 1u;
-#pragma unroll
-    for (int k = 0; k < 15; k++) la += ca >= upper[k] ? 1u : 0u;
+    const uint32_t la = code_len15(ca, upper);
     const uint32_t la_c = min(la, 15u);
     const uint32_t cb = __brev((uint32_t)(br.buf >> la_c)) >> 17;   // (caller: at least 30 bits in buf)
-    uint32_t lb = 1u;
-#pragma unroll
-    for (int k = 0; k < 15; k++) lb += cb >= upper[k] ? 1u : 0u;
+    const uint32_t lb = code_len15(cb, upper);
     const uint32_t lb_c = min(lb, 15u);
     const uint32_t da = t.at(L_DELTA + (int)la_c), db = t.at(L_DELTA + (int)lb_c);
     const uint32_t ia = ((ca >> (15u - la_c)) + da) & 0xFFFFu, ib = ((cb >> (15u - lb_c)) + db) & 0xFFFFu;
     const bool va = la <= 15u && ia < 288u, vb = lb <= 15u && ib < 288u;
-    const uint32_t sa = t.get_litlen(va ? ia : 0u), sb = t.get_litlen(vb ? ib : 0u);
+    uint32_t sa = t.get_litlen(va ? ia : 0u), sb = t.get_litlen(vb ? ib : 0u);
+    // (both symbols are wanted HERE: left alone the compiler sinks b's table reads into the caller's "a is a literal"
+    //  branch, and the pair pays four LDS round trips instead of two)
+    asm volatile("" : "+v"(sa), "+v"(sb));
     return {va ? (int)sa : -1, vb ? (int)sb : -1, la_c, lb_c};
 }
 
@@ -368,6 +404,7 @@ __device__ uint32_t inflate_block(const uint8_t *comp, uint64_t comp_bytes, cons
     }
     uint32_t pos = 0;
     uint32_t lu[15], du[15];   // code-length thresholds of the literal/length and distance codes
+    Upper2 lu2, du2;           // ... packed, for the one-wait loop (code_len15)
     for (;;) {
         br.refill();
         const uint32_t bfinal = br.take(1), btype = br.take(2);
@@ -392,6 +429,7 @@ __device__ uint32_t inflate_block(const uint8_t *comp, uint64_t comp_bytes, cons
                 for (int L = 0; L < 16; L++) { t.at(L_OFFS + L) = 0; t.at(D_DELTA + L) = 0; }
                 t.at(L_OFFS + 7) = 24; t.at(L_OFFS + 8) = 152; t.at(L_OFFS + 9) = 112;
                 (void)huff_finish<15>(t, L_OFFS, L_DELTA, lu);
+                pack_upper(lu, lu2);
                 t.clear_hi();
                 for (int s = 0; s < 288; s++) {
                     const int L = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8;
@@ -403,6 +441,7 @@ __device__ uint32_t inflate_block(const uint8_t *comp, uint64_t comp_bytes, cons
                 for (int L = 0; L < 16; L++) t.at(L_OFFS + L) = 0;
                 t.at(L_OFFS + 5) = 30;
                 (void)huff_finish<15>(t, L_OFFS, D_DELTA, du);
+                pack_upper(du, du2);
                 for (int s = 0; s < 30; s++) t.sym8(D_SYM + s) = (uint8_t)s;
             } else {
                 // dynamic code: HLIT, HDIST, HCLEN, the code-length code, then the two codes' lengths
@@ -447,6 +486,7 @@ __device__ uint32_t inflate_block(const uint8_t *comp, uint64_t comp_bytes, cons
 #pragma unroll
                         for (int L = 0; L < 16; L++) t.at(L_OFFS + L) = lcount[L];
                         if (!huff_finish<15>(t, L_OFFS, L_DELTA, lu)) return INF_BAD_CODES;
+                        pack_upper(lu, lu2);
                         t.clear_hi();
                     } else {
 #pragma unroll
@@ -497,6 +537,7 @@ __device__ uint32_t inflate_block(const uint8_t *comp, uint64_t comp_bytes, cons
 #pragma unroll
                         for (int L = 0; L < 16; L++) t.at(L_OFFS + L) = dcount[L];
                         if (!huff_finish<15>(t, L_OFFS, D_DELTA, du)) return INF_BAD_CODES;
+                        pack_upper(du, du2);
                         for (uint32_t d = 0; d < ndist; d++) {
                             const uint32_t l = (uint32_t)((d < 16u ? dl_lo >> (4u * d) : dl_hi >> (4u * (d - 16u))) & 15ull);
                             if (l) {
@@ -521,6 +562,7 @@ __device__ uint32_t inflate_block(const uint8_t *comp, uint64_t comp_bytes, cons
             uint8_t *pdst = out;
             uint32_t plen = 0, pdist = 0;   // pending piece; pdist != 0: a run of period pdist (< 8) seeded by the 8 bytes in front of pdst
             uint32_t prem = 0, pcap = 0;    // PIECES: bytes of the copy behind the pending piece, and the most one piece may take
+            bool pself = false;             // PIECES: the copy's distance is below a piece's size (it may feed on itself)
             for (;;) {
                 uint64_t ts0 = 0, ts1 = 0, ts2 = 0;
                 if constexpr (STAMP) ts0 = __builtin_amdgcn_s_memtime();
@@ -537,7 +579,7 @@ __device__ uint32_t inflate_block(const uint8_t *comp, uint64_t comp_bytes, cons
                 uint64_t lits = 0;
                 while (!busy && run < lit_run && br.avail() >= 64u) {   // (two literals and a token take at most 30 + 33 bits)
                     br.refill_nomem();
-                    const LitPair lp = litlen_peek2(br, t, lu);
+                    const LitPair lp = litlen_peek2(br, t, lu2);
                     if (lp.a < 0) { sym = -1; break; }
                     br.drop(lp.la);
                     if (lp.a >= 256) { sym = lp.a; break; }
@@ -564,7 +606,7 @@ __device__ uint32_t inflate_block(const uint8_t *comp, uint64_t comp_bytes, cons
                         len = ((4u + ((s - 265u) & 3u)) << e) + 3u + br.take(e);
                     }
                     br.refill_nomem();
-                    const int ds = huff_decode<15, false>(br, t, D_DELTA, D_SYM, 30, du);
+                    const int ds = huff_decode15<false>(br, t, D_DELTA, D_SYM, 30, du2);
                     if (ds < 0 || ds >= 30) return INF_BAD_DISTANCE;   // (>= 30: an unplaced slot of an incomplete code)
                     const uint32_t d = (uint32_t)ds;
                     if (d < 4u) dist = d + 1u;
@@ -625,7 +667,9 @@ __device__ uint32_t inflate_block(const uint8_t *comp, uint64_t comp_bytes, cons
                     } else store_tail16(pdst, (uint64_t)pa.x | ((uint64_t)pa.y << 32), (uint64_t)pa.z | ((uint64_t)pa.w << 32), plen);
                     if (PIECES && prem) {   // the next piece of the same copy (a run's seed is re-read behind the bytes just stored)
                         pdst += plen;
-                        lsrc = pdist ? pdst - 16 : lsrc + plen;
+                        if (pdist) lsrc = pdst - 16;
+                        else if (pself) pcap = 2u * pcap <= INF_PIECE ? 2u * pcap : pcap;   // (the source stays: see below)
+                        else lsrc += plen;
                         plen = min(prem, pcap);
                         prem -= plen;
                     } else {
@@ -655,11 +699,17 @@ __device__ uint32_t inflate_block(const uint8_t *comp, uint64_t comp_bytes, cons
                         pdst = dst; pdist = dist;
                         if constexpr (PIECES) { pcap = INF_PIECE; plen = min(len, pcap); prem = len - plen; }
                         else plen = len;
-                    } else if (PIECES && dist >= 16u) {
-                        // pieces of <= 64 bytes, never longer than the distance: a piece's source lies wholly in front of its
-                        // destination, i.e. in bytes stored (issued) before its request is
+                    } else if (PIECES && dist >= 8u) {
+                        // pieces of <= 64 bytes, never longer than what lies between source and destination: a piece's source
+                        // is wholly in front of its destination, i.e. in bytes stored (issued) before its request is.
+                        // A copy that feeds on itself (dist < 64: the period-8..15 matches of binned quality strings used to be
+                        // copied IN PLACE, 8 bytes per load round trip, with every other lane of the wave waiting -- 1.7 % of
+                        // a lane's steps, i.e. two wave-steps in three) reads every piece from the SAME source: after pieces
+                        // of dist, 2 dist, 4 dist ... bytes the destination is a whole number of periods ahead and twice as
+                        // many valid bytes lie behind the source.
                         lsrc = src;
                         pdst = dst; pdist = 0u;
+                        pself = dist < INF_PIECE;
                         pcap = min(INF_PIECE, dist); plen = min(len, pcap); prem = len - plen;
                     } else if (!PIECES && dist >= 8u && len <= 32u && dist >= len) {
                         // (the 32 bytes requested may run past dst by up to 24: not-yet-written bytes of this block, of
@@ -962,7 +1012,8 @@ __device__ __forceinline__ bool plausible_record(const uint8_t *p, uint64_t avai
 // starting in it, e = where the last of them ends, last = where the last of them starts
 __global__ void __launch_bounds__(256) bgzf_chain_spec(const uint8_t *out, const BgzfBlock *blocks, uint32_t n_blocks, uint64_t data_end,
                                                        const uint64_t *first_start, int32_t n_ref, uint64_t *a, uint32_t *n,
-                                                       uint64_t *e, uint64_t *last, uint32_t *flags) {
+                                                       uint64_t *e, uint64_t *last, uint32_t *flags, uint64_t *sb_words) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) sb_words[0] = sb_words[1] = 0ull;   // this super-batch's "links broken" / "repaired" words
     for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < n_blocks; b += gridDim.x * blockDim.x) {
         const BgzfBlock blk = blocks[b];
         uint64_t a_b = CHAIN_NONE, e_b = 0, last_b = 0;
@@ -1045,16 +1096,22 @@ __global__ void __launch_bounds__(1024) bgzf_chain_suffix(const uint64_t *a, uin
 }
 
 // checks that the per-block chains link up, settles the records of the last block against the end of
-// the data (an incomplete last record is the tail), writes counts[] and the tail's start
+// the data (an incomplete last record is the tail), writes counts[] and the tail's start.
+// Two passes (SECOND = false, true) around bgzf_chain_repair: the first notes broken links in the super-batch's own
+// word (sb_words[0]) for the repair kernel, the second runs only if something was repaired (sb_words[1]) and raises
+// what is still broken then.
+template <bool SECOND>
 __global__ void __launch_bounds__(256) bgzf_chain_verify(const uint8_t *out, const uint32_t *n, const uint64_t *e, const uint64_t *last,
                                                          const uint64_t *nexta, uint32_t n_blocks, uint64_t data_end, const uint64_t *first_start,
-                                                         uint32_t *counts, uint64_t *tail_start, uint32_t *flags) {
+                                                         uint32_t *counts, uint64_t *tail_start, uint32_t *flags, uint64_t *sb_words) {
+    if (SECOND && !sb_words[1]) return;
     for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < n_blocks; b += gridDim.x * blockDim.x) {
         uint32_t c = n[b];
+        bool broken = false;
         if (c) {
             const uint64_t next = nexta[b + 1u];
             if (next != CHAIN_NONE) {
-                if (e[b] != next) atomicOr(flags, FEED_RAGGED);
+                if (e[b] != next) broken = true;
             } else if (e[b] == data_end) *tail_start = data_end;
             else if (e[b] > data_end) { c--; *tail_start = last[b]; }       // the last record runs past the data: the tail
             else if (data_end - e[b] < 4u) *tail_start = e[b];             // a cut-off length word: the tail
@@ -1063,7 +1120,7 @@ __global__ void __launch_bounds__(256) bgzf_chain_verify(const uint8_t *out, con
                 // fields): fine if it is the cut-off tail, a broken chain if it is whole
                 const uint32_t bs = load_u32_unaligned(out + e[b]);
                 if (bs >= 32u && bs <= CHAIN_MAX_RECORD && e[b] + 4ull + bs > data_end) *tail_start = e[b];
-                else atomicOr(flags, FEED_RAGGED);
+                else broken = true;
             }
         }
         counts[b] = c;
@@ -1072,8 +1129,111 @@ __global__ void __launch_bounds__(256) bgzf_chain_verify(const uint8_t *out, con
             // block 0 anchors the chain at *first_start; when it starts no record itself (an empty BGZF block at the
             // head of the stream) the first candidate a LATER block found must be that very offset -- a candidate scan
             // that skipped an implausible record there would drop it silently, where the host reader diagnoses it
-            else if (n[0] == 0u && nexta[0] != *first_start) atomicOr(flags, FEED_RAGGED);
+            else if (n[0] == 0u && nexta[0] != *first_start) broken = true;
         }
+        if (broken) {
+            if (SECOND) atomicOr(flags, FEED_RAGGED);
+            else atomicOr((unsigned long long *)&sb_words[0], 1ull);
+        }
+    }
+}
+
+// Repairs broken links instead of giving the file up.  Every block guessed its first record start on its own; where a
+// guess was wrong (bytes inside a record that look like a chain of records: a B-array of aux data, a long read's
+// qualities) the chain coming from the LEFT is the true one -- block 0 is anchored, and a block whose start is true
+// walks true.  So: find the first broken link, walk the records serially from the true end of the block on its left,
+// rewriting the entries of the blocks passed (none / corrected), until the walk lands exactly on a block's own guess
+// -- from there the guesses are true again -- and go on to the next broken link.  One wave; the search for broken
+// links is 64 blocks wide, the walk is serial (a wrong block costs a walk over its records, ~0.5 ms; a file whose
+// every block is wrong degenerates to the serial chain, as on the host).  Records are judged like the candidates
+// were: one that is implausible, or longer than the carry gap, leaves FEED_RAGGED standing (the host reader words the
+// diagnosis).  PSSBAM_FEED_REPAIR=0 launches the kernel with enabled = 0 (the round-2 behaviour: any broken link
+// raises FEED_RAGGED).
+__global__ void __launch_bounds__(64) bgzf_chain_repair(const uint8_t *out, const BgzfBlock *blocks, uint32_t n_blocks, uint64_t data_end,
+                                                        const uint64_t *first_start, int32_t n_ref, uint64_t *a, uint32_t *n, uint64_t *e,
+                                                        uint64_t *last, const uint64_t *nexta, uint32_t *flags, uint64_t *sb_words, int enabled) {
+    if (!sb_words[0]) return;
+    if (!enabled) {
+        if (threadIdx.x == 0) atomicOr(flags, FEED_RAGGED);
+        return;
+    }
+    const uint32_t lane = threadIdx.x;
+    uint32_t from = 0;             // links left of block `from` hold
+    bool failed = false, any = false;
+    // the anchor: block 0 starts no record, and what the later blocks found does not begin at *first_start
+    uint64_t pos = 0;
+    uint32_t bi = 0;
+    bool walking = false;
+    if (n[0] == 0u && nexta[0] != CHAIN_NONE && nexta[0] != *first_start) { pos = *first_start; bi = 0; walking = true; }
+    for (;;) {
+        if (!walking) {
+            // the next broken link at or behind `from`, 64 blocks at a time
+            uint32_t found = 0xFFFFFFFFu;
+            for (uint32_t base = from; base < n_blocks && found == 0xFFFFFFFFu; base += 64u) {
+                const uint32_t b = base + lane;
+                bool broken = false;
+                if (b < n_blocks && n[b]) {
+                    const uint64_t next = nexta[b + 1u], eb = e[b];
+                    if (next != CHAIN_NONE) broken = eb != next;
+                    else if (eb < data_end && data_end - eb >= 4u) {
+                        const uint32_t bs = load_u32_unaligned(out + eb);
+                        broken = !(bs >= 32u && bs <= CHAIN_MAX_RECORD && eb + 4ull + bs > data_end);
+                    }
+                }
+                const unsigned long long m = __ballot(broken);
+                if (m) found = base + (uint32_t)__ffsll((long long)m) - 1u;
+            }
+            if (found == 0xFFFFFFFFu) break;
+            pos = e[found];
+            bi = found + 1u;
+            walking = true;
+        }
+        // (every lane walks the same addresses; lane 0 writes)
+        any = true;
+        while (bi < n_blocks) {
+            const BgzfBlock blk = blocks[bi];
+            const uint64_t lo = blk.out_off, hi = lo + blk.isize;
+            if (pos >= hi || blk.isize == 0u) {   // no record starts in this block
+                if (lane == 0u) { a[bi] = CHAIN_NONE; n[bi] = 0u; e[bi] = 0ull; last[bi] = 0ull; }
+                bi++;
+                continue;
+            }
+            if (n[bi] && a[bi] == pos) break;     // the block's own guess is the true start: in step again
+            if (pos >= data_end) break;
+            uint64_t first = pos, l = pos;
+            uint32_t k = 0;
+            while (pos < hi) {
+                if (pos + 4u > data_end) break;   // a cut-off length word: the tail
+                const uint32_t bs = load_u32_unaligned(out + pos);
+                const bool near_end = data_end - pos < 36u + 256u;
+                if (!(plausible_record(out + pos, data_end - pos, n_ref) || (near_end && bs >= 32u && bs <= CHAIN_MAX_RECORD))) { failed = true; break; }
+                l = pos;
+                pos += 4ull + bs;
+                k++;
+            }
+            if (failed) break;
+            if (lane == 0u) {
+                a[bi] = k ? first : CHAIN_NONE;
+                n[bi] = k;
+                e[bi] = k ? pos : 0ull;
+                last[bi] = k ? l : 0ull;
+            }
+            if (pos < hi) {   // stopped at the cut-off length word: nothing starts behind it
+                for (uint32_t r = bi + 1u; r < n_blocks; r++)
+                    if (lane == 0u) { a[r] = CHAIN_NONE; n[r] = 0u; e[r] = 0ull; last[r] = 0ull; }
+                bi = n_blocks;
+                break;
+            }
+            bi++;
+        }
+        if (failed) break;
+        walking = false;
+        from = bi;
+        if (bi >= n_blocks) break;
+    }
+    if (lane == 0u) {
+        if (failed) atomicOr(flags, FEED_RAGGED);
+        else if (any) sb_words[1] = 1ull;
     }
 }
 
@@ -1133,6 +1293,21 @@ __global__ void __launch_bounds__(256) bgzf_chain_carry_in(const uint8_t *carry,
     const uint64_t len = min(*tail_len, gap);
     for (uint64_t i = threadIdx.x; i < len; i += blockDim.x) dst_out[gap - len + i] = carry[i];
     if (threadIdx.x == 0) *first_start = gap - len;
+}
+
+// Several engines dealt alternating runs of ONE stream: the partial record engine A's run ends with goes to the engine
+// that gets the next run through a page-locked host buffer both devices can address (_out on A's stream; _in on B's,
+// behind an event).  A keeps nothing: the record is B's to complete and to tally.
+__global__ void __launch_bounds__(256) bgzf_chain_handoff_out(const uint8_t *carry, uint64_t *tail_len, uint8_t *host_buf, uint64_t *host_len) {
+    const uint64_t len = *tail_len;
+    for (uint64_t i = threadIdx.x; i < len; i += blockDim.x) host_buf[i] = carry[i];
+    __syncthreads();
+    if (threadIdx.x == 0) { *host_len = len; *tail_len = 0; }
+}
+__global__ void __launch_bounds__(256) bgzf_chain_handoff_in(const uint8_t *host_buf, const uint64_t *host_len, uint8_t *carry, uint64_t gap, uint64_t *tail_len) {
+    const uint64_t len = min(*host_len, gap);
+    for (uint64_t i = threadIdx.x; i < len; i += blockDim.x) carry[i] = host_buf[i];
+    if (threadIdx.x == 0) *tail_len = len;
 }
 
 // the caller declares that the next blocks do not continue the stream fed so far: a partial record

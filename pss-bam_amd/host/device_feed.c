@@ -371,8 +371,8 @@ int run_device_feed(pssbam_engine *const *eng, int n_gpus, const char *path, siz
                 }
                 const uint64_t end_in = bl[j - 1].in_off + bl[j - 1].in_len;
                 const int g = (int)((n_submits / (uint64_t)run) % (uint64_t)n_gpus);
-                if (n_gpus > 1 && g != last_g) { /* this engine's previous run ended elsewhere in the file: a new record chain */
-                    if (pssbam_engine_feed_break(eng[g])) { fprintf(stderr, "Error: GPU engine: %s\n", pssbam_last_error()); goto done; }
+                if (n_gpus > 1 && g != last_g) { /* the run of engine last_g ends here: the record it may end in is completed by engine g */
+                    if (last_g >= 0 && pssbam_engine_feed_handoff(eng[last_g], eng[g])) { fprintf(stderr, "Error: GPU engine: %s\n", pssbam_last_error()); goto done; }
                     last_g = g;
                 }
                 uint64_t ticket = 0;
@@ -439,9 +439,6 @@ int run_device_feed(pssbam_engine *const *eng, int n_gpus, const char *path, siz
         fs->inflated_bytes += ib;
     }
     if (fs->flags & (PSSBAM_FEED_RAGGED | PSSBAM_FEED_BAD_RECORD)) fs->fallback = 1; /* the host reader follows records across blocks (and words the diagnosis) */
-    else if (n_gpus > 1 && (fs->flags & PSSBAM_FEED_TRUNCATED) && !(fs->flags & PSSBAM_FEED_BAD_BLOCK))
-        fs->fallback = 1; /* several engines, each fed runs of the file: a record crossing from one run into the next
-                             cannot be stitched across devices -- the host reader takes such files */
     else if (fs->flags & PSSBAM_FEED_BAD_BLOCK) { fprintf(stderr, "Error: %s: BGZF inflate / CRC check failed\n", path); goto done; }
     else if (fs->flags & PSSBAM_FEED_TRUNCATED) { fprintf(stderr, "Error: %s: truncated alignment record at end of file\n", path); goto done; }
     if (verbose)

@@ -291,6 +291,136 @@ def test_feed_records_crossing_blocks(pkg, tmp_path, monkeypatch, block, seed):
         assert a == b, (block, super_bytes, got.stats, want.stats)
 
 
+def _bgzf_block_starts(raw):
+    """file offsets of the BGZF blocks of `raw` (BSIZE of the BC subfield, SAM spec 4.1)"""
+    starts, p = [], 0
+    while p < len(raw):
+        starts.append(p)
+        p += int.from_bytes(raw[p + 16:p + 18], "little") + 1
+    assert p == len(raw)
+    return starts
+
+
+@pytest.mark.parametrize("block,seed,n_eng,per_run", [(300, 4, 2, 37), (70, 5, 3, 90), (0xFF00, 6, 2, 1), (5000, 3, 3, 2)])
+def test_feed_handoff_between_engines(pkg, tmp_path, monkeypatch, block, seed, n_eng, per_run):
+    """One BAM in htsjdk's layout dealt to several engines in alternating runs of blocks (what the front end does with
+    n GPUs): the record a run ends in is handed to the engine that gets the next run (pssbam_engine_feed_handoff) and
+    completed there.  Summed tables and status tallies equal the one-engine host path's; no flag is raised; a stream
+    cut inside a record is diagnosed by the engine that holds its last run."""
+    contigs, refs, recs = tl.fuzz_dataset(60 + seed, 2500)
+    bam = tmp_path / "ragged.bam"
+    tl.write_bam(bam, refs, recs, level=1, rng=np.random.default_rng(seed), block=block)
+    raw = bam.read_bytes()
+    hb = _bam_header_bytes(raw)
+    pss, kmer = dict(region_len=15 if seed % 2 else 25), dict(klen=5)
+    eng = pkg.Engine(pss=pss, kmer=kmer)
+    eng.set_genome_arrays(tl.loaded_contigs(contigs))
+    eng.set_references([n for n, _ in refs])
+    eng.submit(tl.raw_records(refs, recs))
+    want = eng.finish()
+    eng.close()
+    monkeypatch.setenv("PSSBAM_FEED_SUPER_BYTES", "1048576")
+
+    def deal(data, header_bytes):
+        starts = _bgzf_block_starts(data) + [len(data)]
+        engs = []
+        for _ in range(n_eng):
+            e = pkg.Engine(pss=pss, kmer=kmer)
+            e.set_genome_arrays(tl.loaded_contigs(contigs))
+            e.set_references([n for n, _ in refs])
+            engs.append(e)
+        # (the first run takes every block the BAM header reaches into, and a few more)
+        ends = np.cumsum([int.from_bytes(data[starts[i + 1] - 4:starts[i + 1]], "little") for i in range(len(starts) - 1)])   # ISIZE
+        first = int(np.searchsorted(ends, header_bytes, side="right"))
+        cuts = [0, first + per_run] + list(range(first + 2 * per_run, len(starts) - 1, per_run)) + [len(starts) - 1]
+        cuts = sorted(set(c for c in cuts if c <= len(starts) - 1))
+        prev = None
+        for r, (b0, b1) in enumerate(zip(cuts[:-1], cuts[1:])):
+            e = engs[r % n_eng]
+            if prev is not None:
+                prev.feed_handoff(e)
+            e.submit_bgzf(np.frombuffer(data[starts[b0]:starts[b1]], dtype=np.uint8), header_bytes=header_bytes if r == 0 else 0)
+            prev = e
+        flags = [e.feed_status()["flags"] for e in engs]
+        tabs = [e.finish() for e in engs]
+        for e in engs:
+            e.close()
+        return flags, tabs, (len(cuts) - 2) % n_eng
+
+    flags, tabs, _ = deal(raw, hb)
+    assert flags == [0] * n_eng, flags
+    assert np.array_equal(sum(t.fwd for t in tabs), want.fwd) and np.array_equal(sum(t.rev for t in tabs), want.rev)
+    assert np.array_equal(sum(t.k5 for t in tabs), want.k5) and np.array_equal(sum(t.k3 for t in tabs), want.k3)
+    got = {}
+    for t in tabs:
+        for k, v in dict(t.stats).items():
+            got[k] = got.get(k, 0) + v
+    b = dict(want.stats)
+    got.pop("slow_path"), b.pop("slow_path")
+    assert got == b, (got, b)
+    assert min(dict(t.stats)["records"] for t in tabs) > 0          # every engine did tally a share
+    # the same stream cut in the middle of a record: only the engine with the last run says so
+    data = tl.bgzf_inflate(raw)
+    cut = data[:int(len(data) * 0.7) + 11]
+    reblocked = b"".join(tl.bgzf_block(cut[i:i + block], 1) for i in range(0, len(cut), block)) + tl.BGZF_EOF
+    flags, _, last = deal(reblocked, hb)
+    assert flags[last] & 8 and all(f == 0 for i, f in enumerate(flags) if i != last), (flags, last)
+
+
+@pytest.mark.parametrize("trailer", [False, True])
+def test_feed_repairs_a_false_record_start(pkg, tmp_path, monkeypatch, trailer):
+    """Bytes INSIDE a record that read like a chain of records (here: a B:C aux array holding the raw bytes of twelve
+    other records) and a BGZF block that begins exactly there: the block's own guess at its first record start is wrong,
+    its chain does not link up with the one coming from the left.  Round 2 gave such a file up (PSSBAM_FEED_RAGGED ->
+    host reader); now bgzf_chain_repair walks the blocks in doubt from the left and the feed carries on -- same tables
+    as the host path, the fake records not tallied.  PSSBAM_FEED_REPAIR=0 shows the input does break the links."""
+    contigs, refs, recs = tl.fuzz_dataset(77, 1200, extras=False)
+    idx = {n: i for i, (n, _) in enumerate(refs)}
+    rng = np.random.default_rng(5)
+    hosts = sorted(int(x) for x in rng.choice(np.arange(50, 1150), 6, replace=False))
+    fake_at = {}
+    for h in hosts:
+        fake = b"".join(tl.bam_record(recs[int(k)], idx) for k in rng.choice(len(recs), 12, replace=False))
+        tags = [("XB", "B", ("C", list(fake)))]
+        if trailer:
+            tags.append(("XZ", "Z", "behind the array"))
+        recs[h] = tl.Rec(**{**recs[h].__dict__, "tags": list(recs[h].tags) + tags})
+        fake_at[h] = fake
+    head = tl.bam_bytes(refs, [])
+    body = [tl.bam_record(r, idx) for r in recs]
+    raw = head + b"".join(body)
+    # block cuts: every 700 bytes, plus one exactly where each fake chain begins
+    starts = np.cumsum([len(head)] + [len(b) for b in body])
+    cuts = set(range(0, len(raw), 700))
+    for h in hosts:
+        at = raw.index(fake_at[h], int(starts[h]))
+        assert at < starts[h + 1]
+        cuts.add(at)
+    cuts = sorted(cuts) + [len(raw)]
+    bgzf = b"".join(tl.bgzf_block(raw[a:b], 6) for a, b in zip(cuts[:-1], cuts[1:])) + tl.BGZF_EOF
+    pss, kmer = dict(region_len=12), dict(klen=4)
+    eng = pkg.Engine(pss=pss, kmer=kmer)
+    eng.set_genome_arrays(tl.loaded_contigs(contigs))
+    eng.set_references([n for n, _ in refs])
+    eng.submit(tl.raw_records(refs, recs))
+    want = eng.finish()
+    eng.close()
+    for super_bytes in (None, "65536"):
+        if super_bytes:
+            monkeypatch.setenv("PSSBAM_FEED_SUPER_BYTES", super_bytes)
+        monkeypatch.setenv("PSSBAM_FEED_REPAIR", "0")
+        _, st = _feed_tables(pkg, contigs, refs, bgzf, len(head), pss, kmer, 30000)
+        assert st["flags"] & 2, st                                  # the links ARE broken
+        monkeypatch.delenv("PSSBAM_FEED_REPAIR")
+        got, st = _feed_tables(pkg, contigs, refs, bgzf, len(head), pss, kmer, 30000)
+        assert st["flags"] == 0, (super_bytes, st)
+        assert np.array_equal(got.fwd, want.fwd) and np.array_equal(got.rev, want.rev)
+        assert np.array_equal(got.k5, want.k5) and np.array_equal(got.k3, want.k3)
+        a, b = dict(got.stats), dict(want.stats)
+        a.pop("slow_path"), b.pop("slow_path")
+        assert a == b, (got.stats, want.stats)
+
+
 def test_feed_flags_damage_and_truncation(pkg, tmp_path):
     """a damaged block raises PSSBAM_FEED_BAD_BLOCK; a stream that ends inside a record raises
     PSSBAM_FEED_TRUNCATED"""
@@ -363,11 +493,16 @@ def test_cli_device_feed_and_fallback(pkg, oracle, tmp_path):
     assert re.search(r"device feed: (\d+) submits", err) and "host reader" not in err
     err = run_pss(aligned, {"PSSBAM_DEVICE_INFLATE": "0"})
     assert "device feed" not in err
-    # two engines are dealt alternating runs of the file: a record crossing from one run into the next cannot
-    # be stitched across devices, so a file in htsjdk's layout goes to the host reader -- same tables
+    # two engines are dealt alternating runs of the file: the record a run ends in is handed to the engine that
+    # gets the next run (pssbam_engine_feed_handoff) -- a file in htsjdk's layout stays on the device feed
     err = run_pss(ragged, {"PSSBAM_CHUNK_BYTES": str(1 << 20), "PSSBAM_NGPU": "2", "PSSBAM_OVERSUBSCRIBE": "1",
                            "PSSBAM_FEED_BATCH_BYTES": str(3 << 20), "PSSBAM_RUN_BATCHES": "2"})
-    assert "falling back to the host reader" in err and "gpus=2" in err
+    assert "falling back to the host reader" not in err and "host reader" not in err and "gpus=2" in err
+    m = re.search(r"submits per engine: (\d+) (\d+)", err)
+    assert m and int(m.group(1)) > 0 and int(m.group(2)) > 0, err[-1500:]
+    err = run_pss(ragged, {"PSSBAM_CHUNK_BYTES": str(1 << 20), "PSSBAM_NGPU": "3", "PSSBAM_OVERSUBSCRIBE": "1", "PSSBAM_NO_EARLY_FEED": "1",
+                           "PSSBAM_FEED_BATCH_BYTES": str(1 << 20), "PSSBAM_RUN_BATCHES": "1", "PSSBAM_FEED_SUPER_BYTES": str(2 << 20)})
+    assert "host reader" not in err and "gpus=3" in err
     pr = subprocess.run([str(b / "fragkon"), "-F", str(fa), "-B", str(aligned)] + ko.argv(), capture_output=True, text=True)
     assert pr.returncode == 0, pr.stderr
     g5, g3 = tl.parse_fragkon_text(pr.stdout)
