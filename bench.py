@@ -39,6 +39,7 @@ import json
 import os
 import re
 import shutil
+import signal
 import socket
 import subprocess
 import sys
@@ -628,6 +629,9 @@ def e2e_leg(pkg, synth, cd, region_len, n_reads, resident_reads, resident_counte
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+E2E_MULTI_TIMEOUT_S = 240   # one run of the n-GPU command (seconds on one GPU with the same file)
+
+
 def e2e_multi(pkg, synth, cd, region_len, n_reads, resident_reads, resident_counters, lay, world):
     """N > 1: `PSSBAM_NGPU=N bin/pss-bam` on the generated level-1 BAM + FASTA of the benchmarked shape -- ONE process
     driving one engine per GPU: the compressed file is dealt in runs of whole super-batches, every GPU inflates, indexes
@@ -655,15 +659,29 @@ def e2e_multi(pkg, synth, cd, region_len, n_reads, resident_reads, resident_coun
         synth.bam_file_host(cfg, 0, n_reads, bam, level=1, threads=threads)
 
         def run_cli(extra):
+            # (a session of its own, killed as a group when it overruns: the command forks a worker that would outlive
+            #  a kill of the process this one started -- and this n-GPU path has never run on n physical GPUs)
             time.sleep(1.0)   # (as in e2e_leg)
             t = time.perf_counter()
-            pr = subprocess.run([str(pkg.PKG_DIR / "bin" / "pss-bam"), "-F", str(fa), "-B", str(bam), "-o", str(tmp / "out"), "-r", str(region_len)],
-                                capture_output=True, text=True, env={**os.environ, "PSSBAM_STATS": "1", "PSSBAM_NGPU": str(world), **extra}, timeout=1500)
-            return pr, time.perf_counter() - t
-        runs = sorted((run_cli({}) for _ in range(3)), key=lambda r: r[1])
-        for r in runs:
-            if r[0].returncode != 0:
-                return {"error": r[0].stderr[-1500:]}
+            po = subprocess.Popen([str(pkg.PKG_DIR / "bin" / "pss-bam"), "-F", str(fa), "-B", str(bam), "-o", str(tmp / "out"), "-r", str(region_len)],
+                                  stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True,
+                                  env={**os.environ, "PSSBAM_STATS": "1", "PSSBAM_NGPU": str(world), **extra})
+            try:
+                so, se = po.communicate(timeout=E2E_MULTI_TIMEOUT_S)
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(po.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+                so, se = po.communicate()
+                return subprocess.CompletedProcess(po.args, -9, so, (se or "") + f"\n[bench] killed after {E2E_MULTI_TIMEOUT_S} s"), time.perf_counter() - t
+            return subprocess.CompletedProcess(po.args, po.returncode, so, se), time.perf_counter() - t
+        runs = []
+        for _ in range(3):
+            runs.append(run_cli({}))
+            if runs[-1][0].returncode != 0:   # (no second try of a run that failed or hung)
+                return {"error": runs[-1][0].stderr[-1500:]}
+        runs.sort(key=lambda r: r[1])
         pr, wall = runs[1]
         grab = lambda pat: (lambda mm: mm.group(1) if mm else None)(re.search(pat, pr.stderr))
         got_f, got_r = tl.parse_counts_text((tmp / "out.pss.counts.txt").read_text())

@@ -198,7 +198,10 @@ int pssbam_engine_genome_kmer_count(pssbam_engine *e, int klen, uint64_t *counts
  * counter blocks of engines[1..n-1] into engines[root] with ONE RCCL ncclReduce(sum,
  * uint64) per device inside a group call over xGMI (communicators from ncclCommInitAll,
  * librccl loaded on first use), after draining every engine's stream.  All engines must
- * have been created with identical options.  n == 1 is a no-op. */
+ * have been created with identical options.  n == 1 is a no-op.  Blocks below 32 MiB (the pss
+ * tables are 7 KB) are summed through the host instead -- n small copies and an add take
+ * microseconds, a communicator over 8 GPUs takes seconds -- unless PSSBAM_REDUCE=rccl;
+ * PSSBAM_REDUCE=host forces the host sum for any size. */
 int pssbam_reduce_counters(pssbam_engine *const *engines, int n, int root);
 
 /* Page-locks a host range (hipHostRegister) so pssbam_engine_submit's copies from it run as

@@ -1245,8 +1245,12 @@ extern "C" int pssbam_reduce_counters(pssbam_engine *const *engines, int n, int 
     bool distinct = true;
     for (int i = 0; i < n; i++)
         for (int j = 0; j < i; j++) distinct = distinct && engines[i]->device != engines[j]->device;
+    // ... and it has to be worth a communicator: ncclCommInitAll over 8 GPUs takes seconds, the pss tables are 7 KB per
+    // engine (8 small copies and a host add: microseconds) -- RCCL carries the block from 32 MiB up (k-mer bins at
+    // k >= 11), or when asked to (PSSBAM_REDUCE=rccl)
     const char *force = getenv("PSSBAM_REDUCE");
-    if (distinct && !(force && !strcmp(force, "host"))) {
+    const bool big = engines[0]->n_counters * sizeof(unsigned long long) >= (32ull << 20);
+    if (distinct && !(force && !strcmp(force, "host")) && (big || (force && !strcmp(force, "rccl")))) {
         const int rc = reduce_rccl(engines, n, root);
         if (rc <= 0) return rc;
     }
