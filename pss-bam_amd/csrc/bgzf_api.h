@@ -328,7 +328,7 @@ std::condition_variable g_feed_reserve_cv;
 
 // Allocates the buffers of the feed's first slots for `device` and publishes them one by one (an engine that needs a
 // slot meanwhile waits for the next one instead of allocating beside this thread: device allocations of this size take
-// from a millisecond to hundreds of ms each, depending on what the driver has to clear -- profiles/r03_exit_teardown.txt).
+// from a millisecond to hundreds of ms each, depending on what the driver has to clear -- profiles/r03_exit_teardown_probe.txt).
 extern "C" int pssbam_feed_reserve(int device) {
     if (device < 0 || device >= 64) return fail(PSSBAM_EINVAL, "device %d out of range", device);
     {

@@ -225,7 +225,7 @@ static int same_config(const pssbam_config *a, const pssbam_config *b)
 /* ---- the exit that does not make the caller wait ---------------------------------------------------------------
  * Once the reports are on disk the command has nothing left to say, but the kernel still needs 0.2-0.3 s to take the
  * process apart (five hardware queues, ~30 GB of device buffers and their page tables, pinned staging slots -- measured
- * with tools/probe/exit_probe.hip and tools/feed_scan.py, profiles/r03_exit_teardown.txt): a third of the whole
+ * with tools/probe/exit_probe.hip and tools/feed_scan.py, profiles/r03_exit_teardown_probe.txt): a third of the whole
  * command on the 200 M-read shape.  So the work runs in a CHILD forked at the very top of main(), before any thread
  * or HIP call exists; the process the caller started only waits for one byte -- the exit status, sent when the
  * tables are written -- and returns it at once, while the child is dismantled in the background.  A child that
