@@ -93,6 +93,7 @@ constexpr uint32_t INF_LAND_BYTES = 5u * 16u * INF_WAVE;
 // lane decodes nothing (its stream position and its literals wait) and the others go on.  Steps get shorter for all 64
 // lanes; a lane with a 150-byte copy spends three of them on it.
 constexpr uint32_t INF_PIECE = 64u;
+constexpr uint32_t INF_RUN_PIECE = 192u;   // ... of a run of period 1, 2 or 4 (no request needed: the pattern sits in registers)
 constexpr uint32_t INF_LDS_BYTES_DEFER = INF_LDS_BYTES + INF_LAND_BYTES;
 static_assert(INF_LDS_BYTES_DEFER * INF_WAVES_PER_CU <= 160u * 1024u, "the waves of the DEFER loop must fit the CU's LDS");
 
@@ -637,22 +638,35 @@ __device__ uint32_t inflate_block(const uint8_t *comp, uint64_t comp_bytes, cons
                         uint4 pb = *(const uint4 *)(land + 16u * INF_WAVE + 16u * lane), pc = *(const uint4 *)(land + 32u * INF_WAVE + 16u * lane),
                               pd = *(const uint4 *)(land + 48u * INF_WAVE + 16u * lane);
                         bool common = true;
+                        const bool loose = (uint32_t)(pdst - out) + ((plen + 15u) & ~15u) <= isize;
                         if (pdist) {
                             uint64_t pat = (((uint64_t)pa.z | ((uint64_t)pa.w << 32)) >> (8u * (8u - pdist))) & ((1ull << (8u * pdist)) - 1ull);
-                            if ((8u % pdist) == 0u) {
+                            if ((pdist & (pdist - 1u)) == 0u) {   // period 1, 2 or 4 (pdist < 8)
                                 pat |= pdist < 2u ? pat << 8 : 0ull;
                                 pat |= pdist < 4u ? pat << 16 : 0ull;
                                 pat |= pat << 32;
                                 pa.x = pa.z = (uint32_t)pat;
                                 pa.y = pa.w = (uint32_t)(pat >> 32);
                                 pb = pc = pd = pa;
+                                // a run's pattern needs no request: its pieces go up to INF_RUN_PIECE bytes (a 150-byte QUAL run of
+                                // one value -- what the named configurations' BAMs consist of by half -- in one step instead of three)
+                                if (plen > INF_PIECE) {
+                                    if (loose) {
+#pragma unroll
+                                        for (uint32_t k = INF_PIECE / 16u; k < INF_RUN_PIECE / 16u; k++)
+                                            if (plen > 16u * k) store_u128(pdst + 16u * k, pa);
+                                    } else {
+                                        store_run(pdst, pat, pdist, plen);
+                                        common = false;
+                                    }
+                                }
                             } else {
                                 store_run(pdst, pat, pdist, plen);   // (periods 3, 5, 6, 7: rare)
                                 common = false;
                             }
                         }
                         if (common) {
-                            if ((uint32_t)(pdst - out) + ((plen + 15u) & ~15u) <= isize) {
+                            if (loose) {
                                 store_u128(pdst, pa);
                                 if (plen > 16u) store_u128(pdst + 16, pb);
                                 if (plen > 32u) store_u128(pdst + 32, pc);
@@ -697,7 +711,7 @@ __device__ uint32_t inflate_block(const uint8_t *comp, uint64_t comp_bytes, cons
                     if (dist < 8u && pos >= 16u) {
                         lsrc = dst - 16;   // (the seed is the upper half of the first plane)
                         pdst = dst; pdist = dist;
-                        if constexpr (PIECES) { pcap = INF_PIECE; plen = min(len, pcap); prem = len - plen; }
+                        if constexpr (PIECES) { pcap = (dist & (dist - 1u)) == 0u ? INF_RUN_PIECE : INF_PIECE;   /* period 1, 2, 4 */ plen = min(len, pcap); prem = len - plen; }
                         else plen = len;
                     } else if (PIECES && dist >= 8u) {
                         // pieces of <= 64 bytes, never longer than what lies between source and destination: a piece's source
