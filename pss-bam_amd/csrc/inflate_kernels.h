@@ -93,7 +93,6 @@ constexpr uint32_t INF_LAND_BYTES = 5u * 16u * INF_WAVE;
 // lane decodes nothing (its stream position and its literals wait) and the others go on.  Steps get shorter for all 64
 // lanes; a lane with a 150-byte copy spends three of them on it.
 constexpr uint32_t INF_PIECE = 64u;
-constexpr uint32_t INF_RUN_PIECE = 192u;   // ... of a run of period 1, 2 or 4 (no request needed: the pattern sits in registers)
 constexpr uint32_t INF_LDS_BYTES_DEFER = INF_LDS_BYTES + INF_LAND_BYTES;
 static_assert(INF_LDS_BYTES_DEFER * INF_WAVES_PER_CU <= 160u * 1024u, "the waves of the DEFER loop must fit the CU's LDS");
 
@@ -598,22 +597,25 @@ __device__ uint32_t inflate_block(const uint8_t *comp, uint64_t comp_bytes, cons
                 if (sym > 256 && sym != 512) {
                     if (sym > 285) return INF_BAD_SYMBOL;
                     br.refill_nomem();
-                    // length: 257..264 -> 3..10; 265..284 -> ((4 + (s-265)%4) << e) + 3 with e = (s-261)/4 extra bits; 285 -> 258
-                    const uint32_t s = (uint32_t)sym;
-                    if (s < 265u) len = s - 254u;
-                    else if (s == 285u) len = 258u;
-                    else {
-                        const uint32_t e = (s - 261u) >> 2;
-                        len = ((4u + ((s - 265u) & 3u)) << e) + 3u + br.take(e);
+                    // length: 257..264 -> 3..10; 265..284 -> ((4 + (s-265)%4) << e) + 3 with e = (s-261)/4 extra bits; 285 -> 258.
+                    // Selects, not branches (a branch region costs a one-wave-per-SIMD kernel half a dozen scalar issue slots,
+                    // and some lane takes each side at every step anyway); take(0) takes nothing.
+                    {
+                        const uint32_t s = (uint32_t)sym;
+                        const bool mid = s >= 265u && s < 285u;
+                        const uint32_t e = mid ? (s - 261u) >> 2 : 0u;
+                        const uint32_t base = mid ? ((4u + ((s - 265u) & 3u)) << e) + 3u : s == 285u ? 258u : s - 254u;
+                        len = base + br.take(e);
                     }
-                    br.refill_nomem();
+                    // (refill_nomem left >= 32 bits, >= 33 unless the buffer was EMPTY; the length took <= 5 of them, the distance
+                    //  code takes <= 15 and its extra bits <= 13: a second refill only in that one case)
+                    if (br.cnt < 28u) br.refill_nomem();
                     const int ds = huff_decode15<false>(br, t, D_DELTA, D_SYM, 30, du2);
                     if (ds < 0 || ds >= 30) return INF_BAD_DISTANCE;   // (>= 30: an unplaced slot of an incomplete code)
-                    const uint32_t d = (uint32_t)ds;
-                    if (d < 4u) dist = d + 1u;
-                    else {
-                        const uint32_t e = (d >> 1) - 1u;
-                        dist = ((2u + (d & 1u)) << e) + 1u + br.take(e);
+                    {
+                        const uint32_t d = (uint32_t)ds;
+                        const uint32_t e = d < 4u ? 0u : (d >> 1) - 1u;
+                        dist = (d < 4u ? d + 1u : ((2u + (d & 1u)) << e) + 1u) + br.take(e);
                     }
                 }
                 // ---- (2): what (0) requested has had the decode phase to arrive
@@ -648,18 +650,9 @@ __device__ uint32_t inflate_block(const uint8_t *comp, uint64_t comp_bytes, cons
                                 pa.x = pa.z = (uint32_t)pat;
                                 pa.y = pa.w = (uint32_t)(pat >> 32);
                                 pb = pc = pd = pa;
-                                // a run's pattern needs no request: its pieces go up to INF_RUN_PIECE bytes (a 150-byte QUAL run of
-                                // one value -- what the named configurations' BAMs consist of by half -- in one step instead of three)
-                                if (plen > INF_PIECE) {
-                                    if (loose) {
-#pragma unroll
-                                        for (uint32_t k = INF_PIECE / 16u; k < INF_RUN_PIECE / 16u; k++)
-                                            if (plen > 16u * k) store_u128(pdst + 16u * k, pa);
-                                    } else {
-                                        store_run(pdst, pat, pdist, plen);
-                                        common = false;
-                                    }
-                                }
+                                // (✗ run pieces of up to 192 bytes -- the pattern needs no request, a 150-byte QUAL run would take one
+                                //  step instead of three -- measured no gain: 289 / 183 / 132 GB/s against 292 / 187 / 134 with 64-byte
+                                //  pieces; eight more conditional stores in every step cost what the steps saved)
                             } else {
                                 store_run(pdst, pat, pdist, plen);   // (periods 3, 5, 6, 7: rare)
                                 common = false;
@@ -711,7 +704,7 @@ __device__ uint32_t inflate_block(const uint8_t *comp, uint64_t comp_bytes, cons
                     if (dist < 8u && pos >= 16u) {
                         lsrc = dst - 16;   // (the seed is the upper half of the first plane)
                         pdst = dst; pdist = dist;
-                        if constexpr (PIECES) { pcap = (dist & (dist - 1u)) == 0u ? INF_RUN_PIECE : INF_PIECE;   /* period 1, 2, 4 */ plen = min(len, pcap); prem = len - plen; }
+                        if constexpr (PIECES) { pcap = INF_PIECE; plen = min(len, pcap); prem = len - plen; }
                         else plen = len;
                     } else if (PIECES && dist >= 8u) {
                         // pieces of <= 64 bytes, never longer than what lies between source and destination: a piece's source

@@ -97,8 +97,25 @@ static int feed_run(int n_gpus);
 
 static void *reserve_main(void *arg)
 {
-    const int n = (int)(intptr_t)arg, have = pssbam_device_count();
-    for (int g = 0; g < n && g < (have > 0 ? have : 1); g++) (void)pssbam_feed_reserve(g); /* best effort */
+    (void)pssbam_feed_reserve((int)(intptr_t)arg); /* best effort */
+    return NULL;
+}
+
+typedef struct {
+    pssbam_config cfg;
+    int32_t n_ref;
+    pssbam_engine **out;
+    int rc, started;
+    char err[400];
+} engine_make_job;
+
+static void *engine_make_main(void *arg)
+{
+    engine_make_job *j = (engine_make_job *)arg;
+    if (pssbam_engine_create(&j->cfg, j->out) || pssbam_engine_feed_open(*j->out, j->n_ref, EF.fasta_bytes)) {
+        j->rc = 1;
+        snprintf(j->err, sizeof j->err, "%s", pssbam_last_error());   /* (the message is this thread's) */
+    }
     return NULL;
 }
 
@@ -106,19 +123,34 @@ static void early_feed_main(void)
 {
     const int n = env_gpu_count(); /* the first HIP call: runtime start-up happens here */
     EF.t_hip = frontend_now_s() - EF.t0;
-    if (!getenv("PSSBAM_OVERSUBSCRIBE")) { /* the feed's device buffers, beside the engine set-up below (detached: it only allocates) */
-        pthread_t th;
-        if (pthread_create(&th, NULL, reserve_main, (void *)(intptr_t)n) == 0) pthread_detach(th);
-    }
-    const bam_header *h = bam_reader_header(early_rd);
     const int have = pssbam_device_count();
+    if (!getenv("PSSBAM_OVERSUBSCRIBE")) /* the feed's device buffers, beside the engine set-up below (detached: they only allocate; one per GPU) */
+        for (int g = 0; g < n && g < (have > 0 ? have : 1); g++) {
+            pthread_t th;
+            if (pthread_create(&th, NULL, reserve_main, (void *)(intptr_t)g) == 0) pthread_detach(th);
+        }
+    const bam_header *h = bam_reader_header(early_rd);
+    /* one engine per GPU, all created at once: a device's first touch (context, queues, code objects) takes ~0.08 s, and
+     * eight of them one after the other would cost more than the whole command does on one GPU */
+    engine_make_job job[64];
+    pthread_t th[64];
     for (int g = 0; g < n; g++) {
-        pssbam_config c = EF.cfg;
-        c.device = have > 0 ? g % have : g;
-        if (pssbam_engine_create(&c, &EF.eng[g]) || pssbam_engine_feed_open(EF.eng[g], h->n_ref, EF.fasta_bytes)) {
-            snprintf(EF.err, sizeof EF.err, "GPU engine %d: %s", g, pssbam_last_error());
+        job[g].cfg = EF.cfg;
+        job[g].cfg.device = have > 0 ? g % have : g;
+        job[g].n_ref = h->n_ref;
+        job[g].out = &EF.eng[g];
+        job[g].rc = 0;
+        job[g].started = g > 0 && pthread_create(&th[g], NULL, engine_make_main, &job[g]) == 0;
+    }
+    for (int g = 0; g < n; g++)
+        if (!job[g].started) (void)engine_make_main(&job[g]);   /* engine 0 here; the others too if a thread could not be had */
+    for (int g = 0; g < n; g++)
+        if (job[g].started) pthread_join(th[g], NULL);
+    for (int g = 0; g < n; g++) {
+        if (job[g].rc) {
+            snprintf(EF.err, sizeof EF.err, "GPU engine %d: %s", g, job[g].err);
             EF.failed = 1;
-            EF.n_gpus = g + (EF.eng[g] != NULL);
+            EF.n_gpus = n;   /* (whatever was created is destroyed with the rest: NULL entries are skipped) */
             early_engines_done();
             return;
         }
