@@ -41,8 +41,9 @@ def zlib_inflate(block: bytes):
 
 
 rng = np.random.default_rng(2026)
-for loop in ("0", "1"):
+for loop, pieces in (("0", "1"), ("1", "1"), ("1", "0")):   # in place / one wait with bounded pieces (the default) / one wait, whole copies
     os.environ["PSSBAM_INFLATE_LOOP"] = loop
+    os.environ["PSSBAM_INFLATE_PIECES"] = pieces
     flagged = passed = 0
     # (a) valid blocks of mixed content with random bit flips / byte splices anywhere in the payload
     for trial in range(args.trials):
@@ -103,5 +104,5 @@ for loop in ("0", "1"):
                       + struct.pack("<II", int(rng.integers(0, 1 << 32)), isize))
     res = pkg.bgzf_inflate(np.frombuffer(b"".join(blocks), dtype=np.uint8))
     assert res["n_blocks"] == args.hostile
-    print(f"loop {loop}: {args.trials} mutated files ({flagged} flagged, {passed} harmless), {args.hostile} hostile blocks: returned, first bad block {res['bad_block']}", flush=True)
+    print(f"loop {loop} pieces {pieces}: {args.trials} mutated files ({flagged} flagged, {passed} harmless), {args.hostile} hostile blocks: returned, first bad block {res['bad_block']}", flush=True)
 print("soak ok")
