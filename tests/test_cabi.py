@@ -91,3 +91,24 @@ def test_bgzf_scan_host_helper(pkg):
     assert m == n - 1 and consumed.value == len(raw) - 28      # (the last block is the 28-byte EOF marker)
     junk = np.frombuffer(b"this is not a BGZF file at all, just some text" * 3, dtype=np.uint8)
     assert L.pssbam_bgzf_scan(junk.ctypes.data, junk.size, None, 0, None, None) < 0
+
+
+def test_null_engines_are_refused_not_dereferenced(pkg):
+    """error convention of the boundary (include/pssbam_hip.h): a null engine is PSSBAM_EINVAL with a message, on every
+    entry point of the compressed feed -- checked here for the ones that touch no GPU before they look at their arguments"""
+    import ctypes as C
+    L = pkg.hip_lib()
+    L.pssbam_last_error.restype = C.c_char_p
+    calls = [("pssbam_engine_feed_handoff", [C.c_void_p, C.c_void_p], (None, None)),
+             ("pssbam_engine_feed_break", [C.c_void_p], (None,)),
+             ("pssbam_engine_feed_open", [C.c_void_p, C.c_int32, C.c_uint64], (None, 3, 0)),
+             ("pssbam_engine_submit_bgzf", [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p], (None, None, 0, None, 0, 0, None)),
+             ("pssbam_engine_feed_status", [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p], (None, None, None, None)),
+             ("pssbam_engine_set_genome_async", [C.c_void_p, C.c_void_p], (None, None)),
+             ("pssbam_engine_genome_wait", [C.c_void_p], (None,))]
+    for name, argtypes, args in calls:
+        f = getattr(L, name)
+        f.argtypes = argtypes
+        f.restype = C.c_int
+        assert f(*args) == -1, name                  # PSSBAM_EINVAL
+        assert L.pssbam_last_error(), name
