@@ -594,6 +594,10 @@ def e2e_leg(pkg, synth, cd, region_len, n_reads, resident_reads, resident_counte
                     real = {"what": "the same command on a BAM with 40-level quality strings, deflate level 6 (synth.bam_file_host quals='full')",
                             "reads": n_real, "bam_bytes": bam.stat().st_size, "wall_s": rr[1][1], "reads_per_s": n_real / rr[1][1],
                             "wall_s_runs": [r[1] for r in rr], "wall_s_is": "median of 3 runs", "device_feed": mm.group(1) if mm else None,
+                            "engine_feed": (lambda m2: m2.group(1) if m2 else None)(re.search(r"engine feed: (.*)\n", rr[1][0].stderr)),
+                            "device_feed_note": "the kernel seconds quoted in device_feed are launch durations; on this file the feed is PCIe-bound and "
+                                                "flushes partial rounds when the device runs dry (engine_feed: share of the lanes filled), so "
+                                                "bytes / kernel seconds understates the kernel (tools/inflate_bench.py: 134 GB/s at whole rounds)",
                             "host_inflate_run": {"wall_s": r_h[1], "reads_per_s": n_real / r_h[1], "tables_identical": bool(same)},
                             "workload_gen_s": t_bam2}
                 else:
@@ -606,8 +610,9 @@ def e2e_leg(pkg, synth, cd, region_len, n_reads, resident_reads, resident_counte
             "deflate_level": 1, "block_layout": "htslib", "host_cpus_effective": effective_cpus(),
             "wall_s": wall, "reads_per_s": n_reads / wall, "wall_s_runs": [r[1] for r in runs], "wall_s_is": "median of 3 runs",
             "gpu_busy_s": gpu_busy_s, "gpu_busy_frac": gpu_busy_s / wall if gpu_busy_s else None,
-            "gpu_busy_is": "sum of kernel time (HIP events around inflate + CRC + record index, and around every tally launch; + 6 ms "
-                           "genome encode / 4-bit pack) of the median run, over its wall seconds",
+            "gpu_busy_is": "kernel time by HIP events: the union of the super-batches' inflate + CRC + record-index intervals (consecutive "
+                           "inflate launches overlap on purpose: a sum would count that twice) + every tally launch + 6 ms genome encode / "
+                           "4-bit pack, of the median run, over its wall seconds",
             "wall_s_foreground_exit": wall_fg if pr_fg.returncode == 0 else None,
             "wall_s_note": "wall_s = until the process the caller started returns (reports written; a forked worker is torn down "
                            "behind it); wall_s_foreground_exit = PSSBAM_DETACH_EXIT=0, one process, teardown included",

@@ -90,6 +90,25 @@ static bool wave_inflate_wanted() {
     return v ? atoi(v) != 0 : false;
 }
 
+// ISIZE + CRC-32 of every inflated block against its trailer (bgzf_crc_kernel: a block per wave)
+static int launch_crc(hipStream_t st, pssbam_bgzf_block *d_blocks, uint32_t n_blocks, void *d_out) {
+    int dev = 0, n_cu = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    uint32_t *xpow = nullptr;
+    int rc = ensure_xpow(dev, &xpow);
+    if (rc) return rc;
+    static bool crc_attr_set[64] = {false};
+    if (!crc_attr_set[dev & 63]) {
+        HIP_TRY(hipFuncSetAttribute((const void *)pssbam::bgzf_crc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pssbam::CRC_LDS_BYTES));
+        crc_attr_set[dev & 63] = true;
+    }
+    const uint32_t cgrid = std::min<uint32_t>((n_blocks + 15) / 16, (uint32_t)n_cu);   // one 16-wave workgroup per CU, a block per wave
+    hipLaunchKernelGGL(pssbam::bgzf_crc_kernel, dim3(cgrid), dim3(1024), pssbam::CRC_LDS_BYTES, st, (const uint8_t *)d_out, (pssbam::BgzfBlock *)d_blocks, n_blocks, xpow);
+    HIP_TRY(hipGetLastError());
+    return PSSBAM_OK;
+}
+
 static int launch_inflate(hipStream_t st, const void *d_comp, uint64_t comp_bytes, pssbam_bgzf_block *d_blocks, uint32_t n_blocks,
                           void *d_out, int check_crc, int loop, uint64_t out_bytes, const WaveBufs *wb = nullptr) {
     if (!n_blocks) return PSSBAM_OK;
@@ -181,19 +200,7 @@ static int launch_inflate(hipStream_t st, const void *d_comp, uint64_t comp_byte
         hipLaunchKernelGGL(pssbam::bgzf_inflate_kernel<false>, dim3(grid), dim3(pssbam::INF_WAVE), pssbam::INF_LDS_BYTES, st, (const uint8_t *)d_comp,
                            comp_bytes, (pssbam::BgzfBlock *)d_blocks, n_blocks, (uint8_t *)d_out, lit_run);
     HIP_TRY(hipGetLastError());
-    if (check_crc) {
-        uint32_t *xpow = nullptr;
-        int rc = ensure_xpow(dev, &xpow);
-        if (rc) return rc;
-        static bool crc_attr_set[64] = {false};
-        if (!crc_attr_set[dev & 63]) {
-            HIP_TRY(hipFuncSetAttribute((const void *)pssbam::bgzf_crc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pssbam::CRC_LDS_BYTES));
-            crc_attr_set[dev & 63] = true;
-        }
-        const uint32_t cgrid = std::min<uint32_t>((n_blocks + 15) / 16, (uint32_t)n_cu);   // one 16-wave workgroup per CU, a block per wave
-        hipLaunchKernelGGL(pssbam::bgzf_crc_kernel, dim3(cgrid), dim3(1024), pssbam::CRC_LDS_BYTES, st, (const uint8_t *)d_out, (pssbam::BgzfBlock *)d_blocks, n_blocks, xpow);
-        HIP_TRY(hipGetLastError());
-    }
+    if (check_crc) return launch_crc(st, d_blocks, n_blocks, d_out);
     return PSSBAM_OK;
 }
 
@@ -538,8 +545,14 @@ static int feed_flush(pssbam_engine *e) {
     }
     HIP_TRY(hipEventRecord(s.copies_done, e->copy_stream));
     HIP_TRY(hipEventRecord(s.copies_done2, e->copy_stream2));
-    HIP_TRY(hipStreamWaitEvent(e->stream, s.copies_done, 0));
-    HIP_TRY(hipStreamWaitEvent(e->stream, s.copies_done2, 0));
+    // The inflate launch can go to one of two streams of its own (PSSBAM_FEED_INFLATE_STREAMS=2: launches take turns, the head
+    // of one fills the CUs the tail of the previous one leaves; CRC / index / tally stay on the engine's stream behind an
+    // event).  ✗ Measured on the 200 M-read command: feed phase 0.340-0.362 s with, 0.337-0.363 s without -- the blocks of a
+    // launch finish close together and the launches were back to back already -- so one queue remains the default.
+    hipStream_t is = e->stream;
+    if (const char *v = getenv("PSSBAM_FEED_INFLATE_STREAMS")) is = atoi(v) >= 2 ? e->inflate_stream[e->flush_seq & 1u] : e->stream;
+    HIP_TRY(hipStreamWaitEvent(is, s.copies_done, 0));
+    HIP_TRY(hipStreamWaitEvent(is, s.copies_done2, 0));
     // the table goes up from page-locked memory: a pageable source makes hipMemcpyAsync wait for everything queued on
     // the stream (the previous super-batch's kernels), and this thread has the next super-batch's copies to issue
     if (s.h_blocks_cap < nb) {
@@ -555,7 +568,19 @@ static int feed_flush(pssbam_engine *e) {
         memcpy(s.h_blocks, s.blocks.data(), nb * sizeof(pssbam_bgzf_block));
         table = s.h_blocks;
     }
-    HIP_TRY(hipMemcpyAsync(s.d_blocks, table, nb * sizeof(pssbam_bgzf_block), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(s.d_blocks, table, nb * sizeof(pssbam_bgzf_block), hipMemcpyHostToDevice, is));
+    hipEvent_t ev0 = take_event(e), ev1 = take_event(e);
+    if (!ev0 || !ev1) return fail(PSSBAM_EHIP, "hipEventCreate failed");
+    if (!e->feed_base_ev) {
+        HIP_TRY(hipEventCreate(&e->feed_base_ev));
+        HIP_TRY(hipEventRecord(e->feed_base_ev, is));
+    }
+    HIP_TRY(hipEventRecord(ev0, is));
+    rc = launch_inflate(is, s.d_comp, s.comp_used, (pssbam_bgzf_block *)s.d_blocks, (uint32_t)nb, s.d_out, 0, INFLATE_LOOP_DEFAULT, data_end - FEED_GAP);
+    if (rc) return rc;
+    if (!s.inflate_done) HIP_TRY(hipEventCreateWithFlags(&s.inflate_done, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(s.inflate_done, is));
+    HIP_TRY(hipStreamWaitEvent(e->stream, s.inflate_done, 0));
     if (e->feed_fresh) {   // the stream's first super-batch: its chain starts behind the BAM header
         const uint64_t first = FEED_GAP + e->feed_skip;
         HIP_TRY(hipMemcpyAsync(s.d_chain, &first, sizeof first, hipMemcpyHostToDevice, e->stream));   // (pageable source: copied before the call returns)
@@ -564,12 +589,10 @@ static int feed_flush(pssbam_engine *e) {
         hipLaunchKernelGGL(pssbam::bgzf_chain_carry_in, dim3(1), dim3(256), 0, e->stream, (const uint8_t *)e->d_carry, (const uint64_t *)e->d_feed_tail,
                            s.d_out, (uint64_t)FEED_GAP, s.d_chain);
     }
-    hipEvent_t ev0 = take_event(e), ev1 = take_event(e);
-    if (!ev0 || !ev1) return fail(PSSBAM_EHIP, "hipEventCreate failed");
-    HIP_TRY(hipEventRecord(ev0, e->stream));
-    rc = launch_inflate(e->stream, s.d_comp, s.comp_used, (pssbam_bgzf_block *)s.d_blocks, (uint32_t)nb, s.d_out, getenv("PSSBAM_NO_CRC") ? 0 : 1,
-                        INFLATE_LOOP_DEFAULT, data_end - FEED_GAP);
-    if (rc) return rc;
+    if (!getenv("PSSBAM_NO_CRC")) {
+        rc = launch_crc(e->stream, (pssbam_bgzf_block *)s.d_blocks, (uint32_t)nb, s.d_out);
+        if (rc) return rc;
+    }
     // the record chain of the whole super-batch: per-block pieces, linked and checked
     const int32_t n_ref = e->have_refs ? e->n_ref : e->feed_n_ref;
     {
@@ -621,6 +644,11 @@ static int feed_flush(pssbam_engine *e) {
     HIP_TRY(hipEventRecord(s.inflated, e->stream));
     e->inflate_events.emplace_back(ev0, ev1);
     e->inflated_bytes += data_end - FEED_GAP;
+    {   // how full the launch was: a block per lane, the kernel's grid is n_cu x INF_WAVES_PER_CU waves, a partial round costs a whole one
+        const uint64_t lanes = (uint64_t)e->n_cu * (uint64_t)pssbam::INF_WAVES_PER_CU * 64ull;
+        e->feed_blocks_launched += nb;
+        e->feed_lanes_launched += (nb + lanes - 1) / lanes * lanes;
+    }
     // the tally: now, or -- inflated ahead of the genome -- when set_references comes
     const bool ready = feed_engine_ready(e);
     for (size_t k = 0; k < s.sub_first.size(); k++) {
@@ -903,18 +931,32 @@ extern "C" int pssbam_engine_feed_status(pssbam_engine *e, uint32_t *flags, doub
         HIP_TRY(hipMemcpy(&tail, e->d_feed_tail, sizeof tail, hipMemcpyDeviceToHost));
         if (tail) f |= pssbam::FEED_TRUNCATED;
     }
-    for (auto &p : e->inflate_events) {
-        float ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ms, p.first, p.second));
-        e->inflate_ms += ms;
-        e->event_pool.push_back(p.first);
-        e->event_pool.push_back(p.second);
+    {   // kernel time of the feed = the UNION of the super-batches' intervals (first inflate instruction .. record index written):
+        // consecutive launches overlap on purpose, a plain sum would count the overlap twice
+        std::vector<std::pair<float, float>> iv;
+        for (auto &p : e->inflate_events) {
+            float a = 0.f, b = 0.f;
+            HIP_TRY(hipEventElapsedTime(&a, e->feed_base_ev, p.first));
+            HIP_TRY(hipEventElapsedTime(&b, e->feed_base_ev, p.second));
+            iv.emplace_back(a, b);
+            e->event_pool.push_back(p.first);
+            e->event_pool.push_back(p.second);
+        }
+        e->inflate_events.clear();
+        std::sort(iv.begin(), iv.end());
+        float hi = -1e30f;
+        for (auto &x : iv) {
+            if (x.second <= hi) continue;
+            e->inflate_ms += x.second - std::max(x.first, hi);
+            hi = x.second;
+        }
+        if (e->feed_base_ev) { (void)hipEventDestroy(e->feed_base_ev); e->feed_base_ev = nullptr; }
     }
-    e->inflate_events.clear();
     if (getenv("PSSBAM_STATS"))
-        fprintf(stderr, "[pssbam] engine feed: %llu super-batches (%llu cut short because the device had run dry) in %zu slots (%llu allocated here), %llu tally launches put off until the genome was set; "
+        fprintf(stderr, "[pssbam] engine feed: %llu super-batches (%llu cut short because the device had run dry; their blocks filled %.0f %% of the lanes of the inflate launches) in %zu slots (%llu allocated here), %llu tally launches put off until the genome was set; "
                         "buffer allocation %.3f, waiting for a busy slot %.3f, flush (block table + launches) %.3f s\n",
-                (unsigned long long)e->flush_seq, (unsigned long long)e->feed_early_flushes, e->feed.size(), (unsigned long long)e->feed_slots_allocated, (unsigned long long)e->feed_deferred_launches,
+                (unsigned long long)e->flush_seq, (unsigned long long)e->feed_early_flushes,
+                e->feed_lanes_launched ? 100.0 * (double)e->feed_blocks_launched / (double)e->feed_lanes_launched : 0.0, e->feed.size(), (unsigned long long)e->feed_slots_allocated, (unsigned long long)e->feed_deferred_launches,
                 e->feed_t_alloc, e->feed_t_wait_busy, e->feed_t_flush);
     if (flags) *flags = f;
     if (inflate_ms) *inflate_ms = e->inflate_ms;

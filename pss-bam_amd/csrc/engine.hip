@@ -110,7 +110,7 @@ struct FeedAcc {  // one super-batch of compressed blocks: assembled chunk by ch
     uint32_t *d_nrecs = nullptr;
     size_t nrecs_cap = 0;
     uint64_t *d_chain = nullptr;             // [0] where this super-batch's chain starts, [1] where its tail starts, [2] links broken, [3] links repaired
-    hipEvent_t consumed = nullptr, copies_done = nullptr, copies_done2 = nullptr, inflated = nullptr;
+    hipEvent_t consumed = nullptr, copies_done = nullptr, copies_done2 = nullptr, inflated = nullptr, inflate_done = nullptr;
     bool busy = false;                       // flushed; its buffers are in use until `consumed`
     bool held = false;                       // ... and its tally launches still wait for the genome (no `consumed` yet)
     uint64_t flush_seq = 0;                  // order of the flushes (the oldest busy slot frees first)
@@ -153,6 +153,8 @@ struct pssbam_engine {
     int device = 0;
     int n_cu = 0;
     hipStream_t stream = nullptr, copy_stream = nullptr, copy_stream2 = nullptr;
+    hipStream_t inflate_stream[2] = {nullptr, nullptr};   // PSSBAM_FEED_INFLATE_STREAMS=2: the feed's inflate launches take turns on these (bgzf_api.h feed_flush; off by default)
+    hipEvent_t feed_base_ev = nullptr;                    // time zero of the feed's kernel intervals (feed_status: their union)
     hipStream_t genome_stream = nullptr;   // genome upload + encode + pack: beside whatever the engine's stream runs
     hipEvent_t genome_ready = nullptr;
     bool genome_wait_pending = false;      // the next tally launch makes the engine's stream wait for genome_ready
@@ -204,6 +206,7 @@ struct pssbam_engine {
     uint64_t feed_out_target = FEED_OUT_TARGET, feed_comp_cap = FEED_COMP_CAP;   // per super-batch
     double feed_t_alloc = 0, feed_t_wait_busy = 0, feed_t_flush = 0;   // host seconds inside the feed (PSSBAM_STATS)
     uint64_t feed_slots_allocated = 0, feed_deferred_launches = 0, feed_early_flushes = 0;
+    uint64_t feed_blocks_launched = 0, feed_lanes_launched = 0;   // blocks inflated / lanes their launches occupied (whole rounds of the kernel's grid)
     uint64_t feed_idle_min_blocks = 8192;   // a super-batch of at least so many blocks is flushed early when the device has run dry ($PSSBAM_FEED_IDLE_BLOCKS, 0 = never)
     uint64_t feed_block_target = 0;   // blocks per super-batch: a whole number of rounds of the inflate kernel's lanes
     std::vector<std::pair<uint64_t, hipEvent_t>> feed_copies;             // (ticket, copy-complete event) of submits
@@ -297,6 +300,8 @@ extern "C" int pssbam_engine_create(const pssbam_config *cfg, pssbam_engine **ou
     HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&e->copy_stream2, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&e->inflate_stream[0], hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&e->inflate_stream[1], hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&e->genome_stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&e->genome_ready, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&e->copied2, hipEventDisableTiming));
@@ -341,6 +346,8 @@ extern "C" int pssbam_engine_create(const pssbam_config *cfg, pssbam_engine **ou
 extern "C" void pssbam_engine_destroy(pssbam_engine *e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
+    for (hipStream_t is : e->inflate_stream)
+        if (is) (void)hipStreamSynchronize(is);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->copy_stream) (void)hipStreamSynchronize(e->copy_stream);
     if (e->copy_stream2) (void)hipStreamSynchronize(e->copy_stream2);
@@ -364,6 +371,7 @@ extern "C" void pssbam_engine_destroy(pssbam_engine *e) {
         if (s.copies_done) (void)hipEventDestroy(s.copies_done);
         if (s.copies_done2) (void)hipEventDestroy(s.copies_done2);
         if (s.inflated) (void)hipEventDestroy(s.inflated);
+        if (s.inflate_done) (void)hipEventDestroy(s.inflate_done);
         delete sp;
     }
     e->feed.clear();
@@ -390,6 +398,9 @@ extern "C" void pssbam_engine_destroy(pssbam_engine *e) {
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
     if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
     if (e->copy_stream2) (void)hipStreamDestroy(e->copy_stream2);
+    for (hipStream_t is : e->inflate_stream)
+        if (is) (void)hipStreamDestroy(is);
+    if (e->feed_base_ev) (void)hipEventDestroy(e->feed_base_ev);
     if (e->genome_stream) (void)hipStreamDestroy(e->genome_stream);
     if (e->genome_ready) (void)hipEventDestroy(e->genome_ready);
     if (e->copied2) (void)hipEventDestroy(e->copied2);
@@ -1019,6 +1030,8 @@ extern "C" int pssbam_engine_sync(pssbam_engine *e) {
     HIP_TRY(hipStreamSynchronize(e->copy_stream2));
     HIP_TRY(hipStreamSynchronize(e->copy_stream));
     HIP_TRY(hipStreamSynchronize(e->genome_stream));
+    HIP_TRY(hipStreamSynchronize(e->inflate_stream[0]));
+    HIP_TRY(hipStreamSynchronize(e->inflate_stream[1]));
     HIP_TRY(hipStreamSynchronize(e->stream));
     const int rc = genome_settle(e);
     if (rc) return rc;
