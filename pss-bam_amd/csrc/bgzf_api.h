@@ -300,11 +300,6 @@ extern "C" int pssbam_bgzf_inflate_host(int device, const void *bgzf, uint64_t n
 // the GENOME is still on its way: inflate, CRC and record index need no reference base, so they run at once and
 // only the tally launches of a super-batch are put off until set_genome + set_references have been called (the
 // ring grows meanwhile, within what the device has free).
-static double feed_now() {
-    timespec ts;
-    clock_gettime(CLOCK_MONOTONIC, &ts);
-    return ts.tv_sec + ts.tv_nsec * 1e-9;
-}
 
 template <class T>
 static int grow(T **ptr, size_t *cap, size_t need, size_t elem = sizeof(T)) {
@@ -543,14 +538,21 @@ static int feed_flush(pssbam_engine *e) {
         HIP_TRY(hipEventCreateWithFlags(&s.copies_done, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&s.copies_done2, hipEventDisableTiming));
     }
+    late_streams(e, false);
     HIP_TRY(hipEventRecord(s.copies_done, e->copy_stream));
-    HIP_TRY(hipEventRecord(s.copies_done2, e->copy_stream2));
+    HIP_TRY(hipEventRecord(s.copies_done2, e->copy_stream2 ? e->copy_stream2 : e->copy_stream));
     // The inflate launch can go to one of two streams of its own (PSSBAM_FEED_INFLATE_STREAMS=2: launches take turns, the head
     // of one fills the CUs the tail of the previous one leaves; CRC / index / tally stay on the engine's stream behind an
     // event).  ✗ Measured on the 200 M-read command: feed phase 0.340-0.362 s with, 0.337-0.363 s without -- the blocks of a
     // launch finish close together and the launches were back to back already -- so one queue remains the default.
     hipStream_t is = e->stream;
-    if (const char *v = getenv("PSSBAM_FEED_INFLATE_STREAMS")) is = atoi(v) >= 2 ? e->inflate_stream[e->flush_seq & 1u] : e->stream;
+    if (const char *v = getenv("PSSBAM_FEED_INFLATE_STREAMS")) {
+        if (atoi(v) >= 2) {
+            for (hipStream_t &q : e->inflate_stream)
+                if (!q) HIP_TRY(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));   // (made on first use: a stream costs milliseconds at start-up)
+            is = e->inflate_stream[e->flush_seq & 1u];
+        }
+    }
     HIP_TRY(hipStreamWaitEvent(is, s.copies_done, 0));
     HIP_TRY(hipStreamWaitEvent(is, s.copies_done2, 0));
     // the table goes up from page-locked memory: a pageable source makes hipMemcpyAsync wait for everything queued on
@@ -787,7 +789,8 @@ extern "C" int pssbam_engine_submit_bgzf(pssbam_engine *e, const void *comp, uin
             if (rc) return rc;
         }
     }
-    hipStream_t cs = (e->ticket_seq & 1u) ? e->copy_stream2 : e->copy_stream;
+    late_streams(e, false);
+    hipStream_t cs = (e->ticket_seq & 1u) && e->copy_stream2 ? e->copy_stream2 : e->copy_stream;
     uint32_t b0 = 0;
     while (b0 < n_blocks) {
         if (e->cur_feed < 0) {

@@ -17,6 +17,8 @@
 #include <ctime>
 #include <map>
 #include <string>
+#include <thread>
+#include <atomic>
 #include <memory>
 #include <mutex>
 #include <vector>
@@ -29,6 +31,11 @@ using namespace pssbam;
 // errors
 // --------------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
+static double feed_now() {   // host seconds, for the PSSBAM_STATS lines
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + ts.tv_nsec * 1e-9;
+}
 
 static int fail(int code, const char *fmt, ...) {
     va_list ap;
@@ -156,6 +163,14 @@ struct pssbam_engine {
     hipStream_t inflate_stream[2] = {nullptr, nullptr};   // PSSBAM_FEED_INFLATE_STREAMS=2: the feed's inflate launches take turns on these (bgzf_api.h feed_flush; off by default)
     hipEvent_t feed_base_ev = nullptr;                    // time zero of the feed's kernel intervals (feed_status: their union)
     hipStream_t genome_stream = nullptr;   // genome upload + encode + pack: beside whatever the engine's stream runs
+    // A HIP stream costs 10-25 ms to create (a hardware queue each): the two that are not needed for the FIRST blocks of a
+    // feed -- the second copy stream and the genome's -- are made by a helper thread while the first blocks go out, and
+    // adopted when they are there (late_streams()).
+    std::thread late_thread;
+    std::atomic<int> late_ready{0};
+    std::mutex late_mu;
+    hipStream_t late_copy2 = nullptr, late_genome = nullptr;
+    bool late_adopted = false;
     hipEvent_t genome_ready = nullptr;
     bool genome_wait_pending = false;      // the next tally launch makes the engine's stream wait for genome_ready
     std::vector<const void *> genome_pins; // host contigs page-locked for an upload still in flight
@@ -252,6 +267,17 @@ static int env_int(const char *name) {
     return v ? atoi(v) : 0;
 }
 
+// the streams made by the helper thread (engine struct): taken over when they are there, or -- wait -- waited for
+static void late_streams(pssbam_engine *e, bool wait) {
+    std::lock_guard<std::mutex> lk(e->late_mu);
+    if (e->late_adopted) return;
+    if (!wait && !e->late_ready.load(std::memory_order_acquire)) return;
+    if (e->late_thread.joinable()) e->late_thread.join();
+    e->copy_stream2 = e->late_copy2;
+    e->genome_stream = e->late_genome;
+    e->late_adopted = true;
+}
+
 extern "C" int pssbam_engine_create(const pssbam_config *cfg, pssbam_engine **out) {
     if (!cfg || !out) return fail(PSSBAM_EINVAL, "null argument");
     *out = nullptr;
@@ -294,20 +320,34 @@ extern "C" int pssbam_engine_create(const pssbam_config *cfg, pssbam_engine **ou
         e->has_rg = true;
     }
     e->cfg.pss.up_ctx = e->cfg.pss.down_ctx = e->cfg.read_group = nullptr;
+    const bool tstat = getenv("PSSBAM_STATS") != nullptr;
+    const double tc0 = tstat ? feed_now() : 0.0;
     hipDeviceProp_t pr;
     HIP_TRY(hipGetDeviceProperties(&pr, dev));
     e->n_cu = pr.multiProcessorCount;
+    const double tc1 = tstat ? feed_now() : 0.0;
     HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&e->copy_stream2, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&e->inflate_stream[0], hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&e->inflate_stream[1], hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&e->genome_stream, hipStreamNonBlocking));
+    if (getenv("PSSBAM_STREAMS_UP_FRONT")) {   // (A/B: all four streams before create returns, as in round 2)
+        HIP_TRY(hipStreamCreateWithFlags(&e->copy_stream2, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&e->genome_stream, hipStreamNonBlocking));
+        e->late_adopted = true;
+    } else {
+        e->late_thread = std::thread([e, dev]() {
+            if (hipSetDevice(dev) == hipSuccess) {
+                if (hipStreamCreateWithFlags(&e->late_copy2, hipStreamNonBlocking) != hipSuccess) e->late_copy2 = nullptr;
+                if (hipStreamCreateWithFlags(&e->late_genome, hipStreamNonBlocking) != hipSuccess) e->late_genome = nullptr;
+            }
+            (void)hipGetLastError();
+            e->late_ready.store(1, std::memory_order_release);
+        });
+    }
     HIP_TRY(hipEventCreateWithFlags(&e->genome_ready, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&e->copied2, hipEventDisableTiming));
     e->own_stream = true;
     HIP_TRY(hipEventCreate(&e->t_begin));
     HIP_TRY(hipEventCreate(&e->t_end));
+    const double tc2 = tstat ? feed_now() : 0.0;
 
     e->rows = (cfg->tally_mask & PSSBAM_TALLY_PSS) ? (uint32_t)cfg->pss.region_len + 2u : 0u;
     e->n_bins = (cfg->tally_mask & PSSBAM_TALLY_KMER) ? (1ull << (2 * cfg->kmer.klen)) : 0ull;
@@ -339,6 +379,9 @@ extern "C" int pssbam_engine_create(const pssbam_config *cfg, pssbam_engine **ou
     e->env_grid_wgs = env_int("PSSBAM_GRID_WGS");
     e->env_pieces = env_int("PSSBAM_PIECES");
     if (getenv("PSSBAM_COMPACT")) e->use_compact = env_int("PSSBAM_COMPACT") != 0;
+    if (tstat)
+        fprintf(stderr, "[pssbam] engine on device %d: device properties %.3f, 2 streams + events %.3f, counters + scratch (first allocations, first "
+                        "enqueue) %.3f s\n", dev, tc1 - tc0, tc2 - tc1, feed_now() - tc2);
     *out = guard.release();
     return PSSBAM_OK;
 }
@@ -346,6 +389,7 @@ extern "C" int pssbam_engine_create(const pssbam_config *cfg, pssbam_engine **ou
 extern "C" void pssbam_engine_destroy(pssbam_engine *e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
+    late_streams(e, true);
     for (hipStream_t is : e->inflate_stream)
         if (is) (void)hipStreamSynchronize(is);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
@@ -465,6 +509,8 @@ static int genome_upload(pssbam_engine *e, size_t n, const char *const *ids, con
         if (e->d_genome4) { HIP_TRY(hipFree(e->d_genome4)); e->d_genome4 = nullptr; }
     }
     HIP_TRY(hipMalloc(&e->d_genome, total));
+    late_streams(e, true);
+    if (!e->genome_stream) HIP_TRY(hipStreamCreateWithFlags(&e->genome_stream, hipStreamNonBlocking));
     hipStream_t gs = e->genome_stream;
     if (seqs_on_device) {   // the caller's device arrays were written on ITS stream (the engine's, after set_stream)
         hipEvent_t ev = take_event(e);
@@ -527,7 +573,7 @@ extern "C" int pssbam_engine_set_genome_arrays(pssbam_engine *e, size_t n, const
                                                int seqs_on_device) {
     int rc = genome_upload(e, n, ids, seqs, lens, seqs_on_device);
     if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(e->genome_stream));   // the caller may release its arrays when this returns
+    if (e->genome_stream) HIP_TRY(hipStreamSynchronize(e->genome_stream));   // the caller may release its arrays when this returns
     return genome_settle(e);
 }
 
@@ -554,7 +600,7 @@ extern "C" int pssbam_engine_set_genome_async(pssbam_engine *e, const struct gen
 extern "C" int pssbam_engine_genome_wait(pssbam_engine *e) {
     if (!e) return fail(PSSBAM_EINVAL, "null engine");
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipStreamSynchronize(e->genome_stream));
+    if (e->genome_stream) HIP_TRY(hipStreamSynchronize(e->genome_stream));
     return genome_settle(e);
 }
 
@@ -943,7 +989,8 @@ extern "C" int pssbam_engine_submit_async(pssbam_engine *e, const void *records,
     // H2D on the copy stream so it overlaps the previous block's kernel
     // large blocks go over two copy streams (two DMA engines): one stream alone does not fill
     // the PCIe link
-    const uint64_t half = (nbytes >= (64ull << 20) && !getenv("PSSBAM_ONE_COPY_STREAM")) ? (nbytes / 2) & ~4095ull : 0;
+    late_streams(e, false);
+    const uint64_t half = (nbytes >= (64ull << 20) && e->copy_stream2 && !getenv("PSSBAM_ONE_COPY_STREAM")) ? (nbytes / 2) & ~4095ull : 0;
     HIP_TRY(hipEventRecord(s.copy_begin, e->copy_stream));
     if (half) {
         HIP_TRY(hipStreamWaitEvent(e->copy_stream2, s.copy_begin, 0));
@@ -1027,11 +1074,11 @@ extern "C" int pssbam_engine_sync(pssbam_engine *e) {
         const int rc = feed_flush(e);   // compressed blocks still being collected (pssbam_engine_submit_bgzf)
         if (rc) return rc;
     }
-    HIP_TRY(hipStreamSynchronize(e->copy_stream2));
+    if (e->copy_stream2) HIP_TRY(hipStreamSynchronize(e->copy_stream2));
     HIP_TRY(hipStreamSynchronize(e->copy_stream));
-    HIP_TRY(hipStreamSynchronize(e->genome_stream));
-    HIP_TRY(hipStreamSynchronize(e->inflate_stream[0]));
-    HIP_TRY(hipStreamSynchronize(e->inflate_stream[1]));
+    if (e->genome_stream) HIP_TRY(hipStreamSynchronize(e->genome_stream));
+    for (hipStream_t q : e->inflate_stream)
+        if (q) HIP_TRY(hipStreamSynchronize(q));
     HIP_TRY(hipStreamSynchronize(e->stream));
     const int rc = genome_settle(e);
     if (rc) return rc;

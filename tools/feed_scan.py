@@ -52,7 +52,7 @@ for st in settings:
         k, v = kv.split("=", 1)
         env[k] = v
     best = None
-    for rep in range(2):
+    for rep in range(int(os.environ.get("SCAN_REPS", "2"))):
         time.sleep(float(os.environ.get("SCAN_GAP_S", "1.0")))   # the previous run's worker / teardown is out of the way
         t = time.perf_counter()
         pr = subprocess.run([str(pkg.PKG_DIR / "bin" / "pss-bam"), "-F", str(fa), "-B", str(bam), "-o", str(tmp / "o"), "-r", str(region_len)],
@@ -78,7 +78,8 @@ for st in settings:
                       "fasta_load_s": float(fl.group(1)) if fl else None,
                       "early_feed": (lambda m_: m_.group(1) if m_ else None)(re.search(r"early feed \(helper thread[^:]*\): (.*)\n", best[1])),
                       "process": (lambda m_: m_.group(1) if m_ else None)(re.search(r"process creation to main\(\): (.*)\n", best[1])),
-                      "device": (lambda m_: m_.group(1) if m_ else None)(re.search(r"\[pssbam\] device: (.*)\n", best[1]))}), flush=True)
+                      "device": (lambda m_: m_.group(1) if m_ else None)(re.search(r"\[pssbam\] device: (.*)\n", best[1])),
+                      "engine_create": re.findall(r"engine on device (.*)\n", best[1])}), flush=True)
 for p in tmp.iterdir():
     p.unlink()
 tmp.rmdir()
