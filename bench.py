@@ -526,13 +526,14 @@ def e2e_leg(pkg, synth, cd, region_len, n_reads, resident_reads, resident_counte
 
         # the same command with the inflate kept on the host threads (round 1's feed), for comparison
         pr_h, wall_h = run_cli({"PSSBAM_DEVICE_INFLATE": "0"}, "out_host")
-        # three runs of the command as a user would type it; the MEDIAN one is reported (its stages too):
-        # the feed's share of the wall clock moves with what the box's other tenants do to the host side
-        runs = sorted((run_cli({}, "out") for _ in range(3)), key=lambda r: r[1])
+        # five runs of the command as a user would type it; the MEDIAN one is reported (its stages too): the feed's share
+        # of the wall clock moves with what the box's other tenants do to the host side (about one run in eight has its
+        # feeding thread held up for 0.1 s; with three runs the median was one of those every other time)
+        runs = sorted((run_cli({}, "out") for _ in range(5)), key=lambda r: r[1])
         for r in runs:
             if r[0].returncode != 0:
                 return {"error": r[0].stderr[-1500:]}
-        pr, wall = runs[1]
+        pr, wall = runs[2]
         # the same with the teardown in the foreground (by default the process the caller started returns when the
         # reports are written and a forked worker is dismantled behind it: host/frontend.c frontend_detach_start)
         pr_fg, wall_fg = run_cli({"PSSBAM_DETACH_EXIT": "0"}, "out_fg")
@@ -608,7 +609,7 @@ def e2e_leg(pkg, synth, cd, region_len, n_reads, resident_reads, resident_counte
             "command": "bin/pss-bam -F ref.fa -B reads.bam -o out -r %d" % region_len,
             "reads": n_reads, "bam_bytes": bam_bytes, "fasta_bytes": fa.stat().st_size,
             "deflate_level": 1, "block_layout": "htslib", "host_cpus_effective": effective_cpus(),
-            "wall_s": wall, "reads_per_s": n_reads / wall, "wall_s_runs": [r[1] for r in runs], "wall_s_is": "median of 3 runs",
+            "wall_s": wall, "reads_per_s": n_reads / wall, "wall_s_runs": [r[1] for r in runs], "wall_s_is": "median of 5 runs",
             "gpu_busy_s": gpu_busy_s, "gpu_busy_frac": gpu_busy_s / wall if gpu_busy_s else None,
             "gpu_busy_is": "kernel time by HIP events: the union of the super-batches' inflate + CRC + record-index intervals (consecutive "
                            "inflate launches overlap on purpose: a sum would count that twice) + every tally launch + 6 ms genome encode / "

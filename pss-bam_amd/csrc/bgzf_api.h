@@ -577,7 +577,7 @@ static int feed_flush(pssbam_engine *e) {
         HIP_TRY(hipEventCreate(&e->feed_base_ev));
         HIP_TRY(hipEventRecord(e->feed_base_ev, is));
     }
-    HIP_TRY(hipEventRecord(ev0, is));
+    HIP_TRY(hipEventRecord(ev0, is));   // (behind the table's copy: the interval is kernels only, not the copy's wait for a DMA engine)
     rc = launch_inflate(is, s.d_comp, s.comp_used, (pssbam_bgzf_block *)s.d_blocks, (uint32_t)nb, s.d_out, 0, INFLATE_LOOP_DEFAULT, data_end - FEED_GAP);
     if (rc) return rc;
     if (!s.inflate_done) HIP_TRY(hipEventCreateWithFlags(&s.inflate_done, hipEventDisableTiming));
