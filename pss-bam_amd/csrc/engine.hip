@@ -242,6 +242,7 @@ struct pssbam_engine {
     // tuning overrides (environment, for experiments)
     int env_tile_reads = 0, env_grid_mult = 0, env_simple_blocks = 0, env_grid_wgs = 0, env_pieces = 0;
     bool warned_ablate = false;
+    bool compact_plan_once = false;   // tally_compact: header decode + filters once per read, plan through LDS (PSSBAM_COMPACT_PLAN_ONCE)
     uint32_t prep_lds[32] = {0};    // prep_kernel's memo, by kernel variant
     int prep_occ[32] = {0};
     bool use_compact = true;        // -r N <= 16: tally_compact (PSSBAM_COMPACT=0 keeps tally_tiled, for A/B runs)
@@ -379,6 +380,7 @@ extern "C" int pssbam_engine_create(const pssbam_config *cfg, pssbam_engine **ou
     e->env_grid_wgs = env_int("PSSBAM_GRID_WGS");
     e->env_pieces = env_int("PSSBAM_PIECES");
     if (getenv("PSSBAM_COMPACT")) e->use_compact = env_int("PSSBAM_COMPACT") != 0;
+    if (getenv("PSSBAM_COMPACT_PLAN_ONCE")) e->compact_plan_once = env_int("PSSBAM_COMPACT_PLAN_ONCE") != 0;
     if (tstat)
         fprintf(stderr, "[pssbam] engine on device %d: device properties %.3f, 2 streams + events %.3f, counters + scratch (first allocations, first "
                         "enqueue) %.3f s\n", dev, tc1 - tc0, tc2 - tc1, feed_now() - tc2);
@@ -877,9 +879,10 @@ static int launch_tally(pssbam_engine *e, const uint8_t *d_recs, uint64_t nbytes
     } while (0)
         P.row_base = 0;
         // -r N <= 16 (2 context rows + 16 positions): the short-window variant, one pass
-#define LAUNCH_COMPACT(KM, LK)                                                                             \
+#define LAUNCH_COMPACT(KM, LK) do { if (e->compact_plan_once) LAUNCH_COMPACT_(KM, LK, true, 24); else LAUNCH_COMPACT_(KM, LK, false, 16); } while (0)
+#define LAUNCH_COMPACT_(KM, LK, ONCE, VAR)                                                           \
     do {                                                                                           \
-        rc = prep_kernel(e, 16 | (KM ? 2 : 0) | (LK ? 1 : 0), tally_compact<KM, LK>, lds, &occ);   \
+        rc = prep_kernel(e, VAR | (KM ? 2 : 0) | (LK ? 1 : 0), tally_compact<KM, LK, ONCE>, lds, &occ); \
         if (rc == PSSBAM_OK) {                                                                     \
             uint32_t grid = (uint32_t)std::min<uint64_t>(n_tiles, (uint64_t)e->n_cu * occ * mult); \
             if (e->env_grid_wgs > 0) grid = (uint32_t)std::min<uint64_t>(n_tiles, (uint64_t)e->env_grid_wgs); \
@@ -891,13 +894,23 @@ static int launch_tally(pssbam_engine *e, const uint8_t *d_recs, uint64_t nbytes
                 HIP_TRY(hipMalloc(&e->d_scratch, e->scratch_slots * SCRATCH_WORDS * sizeof(uint32_t))); \
             }                                                                                      \
             P.scratch = e->d_scratch;                                                              \
-            hipLaunchKernelGGL((tally_compact<KM, LK>), dim3(grid), dim3(TILED_THREADS), lds, e->stream, P); \
+            hipLaunchKernelGGL((tally_compact<KM, LK, ONCE>), dim3(grid), dim3(TILED_THREADS), lds, e->stream, P); \
             hipLaunchKernelGGL(reduce_partials, dim3((SCRATCH_WORDS * REDUCE_GROUPS + 255) / 256), dim3(256), 0, e->stream, P, grid, \
                                (uint32_t)(LK ? 1 : 0));                                            \
         }                                                                                          \
     } while (0)
         if (do_pss && e->rows <= COMPACT_MAX_ROWS && e->use_compact && !e->has_rg) {
-            if (!do_kmer) LAUNCH_COMPACT(false, false);
+            if (!do_kmer && getenv("PSSBAM_COMPACT_DECODE_TWICE")) {   // diagnostics: what the shared header decode costs
+                rc = prep_kernel(e, 20, tally_compact_decode_twice, lds, &occ);
+                if (rc == PSSBAM_OK) {
+                    const uint32_t grid = (uint32_t)std::min<uint64_t>(n_tiles, (uint64_t)e->n_cu * occ * mult);
+                    if (e->scratch_slots >= grid) {
+                        P.scratch = e->d_scratch;
+                        hipLaunchKernelGGL(tally_compact_decode_twice, dim3(grid), dim3(TILED_THREADS), lds, e->stream, P);
+                        hipLaunchKernelGGL(reduce_partials, dim3((SCRATCH_WORDS * REDUCE_GROUPS + 255) / 256), dim3(256), 0, e->stream, P, grid, 0u);
+                    } else rc = fail(PSSBAM_ESTATE, "scratch too small for the diagnostic kernel");
+                }
+            } else if (!do_kmer) LAUNCH_COMPACT(false, false);
             else if (kmer_lds) LAUNCH_COMPACT(true, true);
             else LAUNCH_COMPACT(true, false);
         } else

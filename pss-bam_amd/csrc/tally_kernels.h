@@ -673,7 +673,7 @@ __device__ __attribute__((noinline)) uint32_t tally_overflow_record_compact(cons
     return record_events(true, DO_KMER, gpl, kfail);
 }
 
-template <bool DO_KMER, bool LDS_KMER>
+template <bool DO_KMER, bool LDS_KMER, int DECODE_REPS = 1, bool PLAN_ONCE = false>
 __device__ __forceinline__ void tally_compact_body(const TallyParams &P, const TallyParams *kernarg,
                                                    uint8_t *__restrict__ stage, uint8_t *__restrict__ sheet,
                                                    uint32_t *__restrict__ table, uint32_t *__restrict__ toffs,
@@ -741,6 +741,50 @@ __device__ __forceinline__ void tally_compact_body(const TallyParams &P, const T
         // ---- CODES, part A: everything that reads `stage` --------------------------------------
         const uint32_t j = tid >> 1, e = tid & 1u;
         const bool lane_on = tid < 2u * T;
+        Plan pl;
+        uint32_t l_seq = 0, soff = 0;   // SEQ length; LDS offset of the SEQ bytes of the staged record
+        bool in_stage = false;
+        if constexpr (PLAN_ONCE) {
+            // A1: ONE lane per read (waves 0 and 1 of the four) decodes the header and applies the filters; the plan -- eight
+            // words -- goes to LDS, where the code sheet will be written later (free between the previous tile's COLUMNS and
+            // this tile's part B), and after one more barrier BOTH lanes of the read's pair pick it up.  The pair used to do
+            // all of this twice, side by side: 17.6 % of the kernel's time on C4 (tools/ab_decode_twice.sh).
+            uint4 *plan_lds = (uint4 *)sheet;
+            if (tid < T) {
+                const bool in_t = tid < count;
+                uint32_t o0 = 0, o1 = 0;
+                if (in_t) { o0 = cur_offs[tid]; o1 = cur_offs[tid + 1]; }
+                const uint32_t avail = pieces * 16u - (o0 & 15u);
+                const bool hdr_ok = in_t && o1 - o0 >= 36u && avail >= 48u;
+                LdsBytes src{stage, hdr_ok ? tid * pieces * 16u + (o0 & 15u) : 0u};
+                const RecHdr h = decode_hdr_lds32(src, hdr_ok ? o1 - o0 : 0u);
+                const bool staged = hdr_ok && h.qual_off + 1u <= avail;
+                Plan p1 = plan_head<true, DO_KMER, false>(P, src, h, RefsLdsCached{refs_lds, P.ref_info, n_ref_cached, (uint32_t)P.n_ref});
+                if (!staged) { p1.status = RS_LIVE; p1.live = p1.pss_cand = p1.fk5 = p1.fk3 = false; }
+                if (in_t && !staged) ovf_list[atomicAdd(ovf_n, 1u)] = tid;   // handled behind COLUMNS (below)
+                const uint32_t bits = (p1.flag & 0xFFFFu) | (p1.status << 16) | (p1.live ? 1u << 18 : 0u) | (p1.pss_cand ? 1u << 19 : 0u) |
+                                      (p1.fk5 ? 1u << 20 : 0u) | (p1.fk3 ? 1u << 21 : 0u) | (staged ? 1u << 22 : 0u);
+                plan_lds[2u * tid] = make_uint4((uint32_t)p1.gbase, (uint32_t)(p1.gbase >> 32), (uint32_t)p1.s, p1.L);
+                plan_lds[2u * tid + 1u] = make_uint4(h.l_seq, src.off + h.seq_off, bits, p1.Lk);
+            }
+            __syncthreads();
+            const uint4 qa = plan_lds[2u * j], qb = plan_lds[2u * j + 1u];   // (j < 128: inside the sheet whatever T is)
+            pl.gbase = (uint64_t)qa.x | ((uint64_t)qa.y << 32);
+            pl.s = (int32_t)qa.z;
+            pl.L = qa.w;
+            l_seq = qb.x;
+            soff = qb.y;
+            pl.flag = qb.z & 0xFFFFu;
+            pl.status = (qb.z >> 16) & 3u;
+            pl.live = lane_on && ((qb.z >> 18) & 1u);
+            pl.pss_cand = lane_on && ((qb.z >> 19) & 1u);
+            pl.fk5 = lane_on && ((qb.z >> 20) & 1u);
+            pl.fk3 = lane_on && ((qb.z >> 21) & 1u);
+            in_stage = lane_on && ((qb.z >> 22) & 1u);
+            pl.Lk = qb.w;
+            pl.rev = (pl.flag & FL_REVERSE) != 0;
+            pl.pss_fwd = pl.pss_rev = false;
+        } else {
         const bool in_tile = lane_on && j < count;
         uint32_t o0 = 0, o1 = 0;
         if (in_tile) { o0 = cur_offs[j]; o1 = cur_offs[j + 1]; }
@@ -749,9 +793,28 @@ __device__ __forceinline__ void tally_compact_body(const TallyParams &P, const T
         LdsBytes src{stage, hdr_ok ? j * pieces * 16u + (o0 & 15u) : 0u};
         const RecHdr h = decode_hdr_lds32(src, hdr_ok ? o1 - o0 : 0u);
         const uint32_t needed = h.qual_off + 1u;   // (the -R filter, which walks the aux fields, stays with tally_tiled)
-        const bool in_stage = hdr_ok && needed <= avail;
-        Plan pl = plan_head<true, DO_KMER, false>(P, src, h, RefsLdsCached{refs_lds, P.ref_info, n_ref_cached, (uint32_t)P.n_ref});
+        in_stage = hdr_ok && needed <= avail;
+        pl = plan_head<true, DO_KMER, false>(P, src, h, RefsLdsCached{refs_lds, P.ref_info, n_ref_cached, (uint32_t)P.n_ref});
+        if constexpr (DECODE_REPS > 1) {
+            // diagnostics (PSSBAM_COMPACT_DECODE_TWICE): header decode + filters a second time, from an offset the
+            // compiler cannot tell from the first -- the time this adds is what the pair's shared decode costs per tile
+            uint32_t off2 = src.off;
+            asm volatile("" : "+v"(off2));
+            const LdsBytes src2{stage, off2};
+            const RecHdr h2 = decode_hdr_lds32(src2, hdr_ok ? o1 - o0 : 0u);
+            const Plan p2 = plan_head<true, DO_KMER, false>(P, src2, h2, RefsLdsCached{refs_lds, P.ref_info, n_ref_cached, (uint32_t)P.n_ref});
+            const uint32_t sink = (uint32_t)p2.s ^ p2.L ^ p2.flag ^ (uint32_t)p2.gbase ^ (uint32_t)(p2.gbase >> 32) ^ p2.status ^ (p2.pss_cand ? 1u : 0u) ^
+                                  (p2.rev ? 2u : 0u) ^ (p2.fk5 ? 4u : 0u) ^ (p2.fk3 ? 8u : 0u) ^ h2.seq_off ^ h2.qual_off;
+            asm volatile("" ::"v"(sink));
+        }
         if (!in_stage) { pl.status = RS_LIVE; pl.live = pl.pss_cand = pl.fk5 = pl.fk3 = false; }
+        l_seq = h.l_seq;
+        soff = src.off + h.seq_off;
+        // a record whose needed prefix is not staged is queued and handled after COLUMNS, where
+        // almost nothing is live (the out-of-line call would otherwise sit in the register-hungry
+        // middle of the tile)
+        if (in_tile && !in_stage && e == 0u) ovf_list[atomicAdd(ovf_n, 1u)] = j;
+        }
         const bool cand = pl.pss_cand;
         // this end's 16 positions + 2 context bases: 18 nibbles of the packed reference from
         //   left : s-2 .. s+15      (nibbles 0,1 = second, first context base; 2..17 = positions 0..15)
@@ -773,8 +836,8 @@ __device__ __forceinline__ void tally_compact_body(const TallyParams &P, const T
         uint32_t rr[3] = {0u, 0u, 0u};
         uint32_t ssh = 0u;
         if (cand) {
-            const int32_t n0a = min(n0, (int32_t)h.l_seq);
-            const uint32_t sa = src.off + (uint32_t)((int32_t)h.seq_off + (n0a >> 1));
+            const int32_t n0a = min(n0, (int32_t)l_seq);
+            const uint32_t sa = soff + (uint32_t)(n0a >> 1);
             const uint32_t *qs = (const uint32_t *)(stage + (sa & ~3u));
             ssh = sa & 3u;
 #pragma unroll
@@ -793,10 +856,6 @@ __device__ __forceinline__ void tally_compact_body(const TallyParams &P, const T
             for (int k = 0; k < 3; k++) kw[k] = kq.v[k];
             ksh = 4u * (uint32_t)(ka & 7ull);
         }
-        // a record whose needed prefix is not staged is queued and handled after COLUMNS, where
-        // almost nothing is live (the out-of-line call would otherwise sit in the register-hungry
-        // middle of the tile)
-        if (in_tile && !in_stage && e == 0u) ovf_list[atomicAdd(ovf_n, 1u)] = j;
         // consume the gathered registers before the next DMA is issued (vmcnt retires in order)
         uint32_t A[3];  // nibble q of A[m] = window nibble 8m + q
 #pragma unroll
@@ -865,7 +924,7 @@ __device__ __forceinline__ void tally_compact_body(const TallyParams &P, const T
                     GO[m] = __builtin_amdgcn_perm(0xFFFFFFFFu, 0x00020406u, (Gw[m] >> 4) & M);
                 }
                 // bases at or beyond l_seq do not exist (precondition P3): blank them
-                const int32_t have_s = (int32_t)h.l_seq - n0;
+                const int32_t have_s = (int32_t)l_seq - n0;
                 const uint32_t have = have_s <= 0 ? 0u : have_s >= 16 ? 16u : (uint32_t)have_s;
                 if (__any(have < 16u)) {
 #pragma unroll
@@ -980,7 +1039,7 @@ __device__ __forceinline__ void tally_compact_body(const TallyParams &P, const T
     if (tid < 16u) mine[SCRATCH_DELTA + tid] = tid < (uint32_t)ST_USED ? (uint32_t)lds_delta[tid] : 0u;
 }
 
-template <bool DO_KMER, bool LDS_KMER>
+template <bool DO_KMER, bool LDS_KMER, bool PLAN_ONCE = false>
 __global__ void __launch_bounds__(TILED_THREADS) tally_compact(const TallyParams P) {
     extern __shared__ __attribute__((aligned(16))) uint8_t stage[];
     __shared__ __attribute__((aligned(16))) uint8_t sheet[TILED_MAX_T * 32u];
@@ -992,8 +1051,24 @@ __global__ void __launch_bounds__(TILED_THREADS) tally_compact(const TallyParams
     __shared__ uint32_t ctx_rep[CTX_WORDS];
     __shared__ uint32_t ovf_list[TILED_MAX_T + 1];   // [TILED_MAX_T] = fill count
     const TallyParams *kernarg = (const TallyParams *)__builtin_amdgcn_kernarg_segment_ptr();
-    tally_compact_body<DO_KMER, LDS_KMER>(P, kernarg, stage, sheet, table, toffs, lds_kmer, lds_delta, refs_lds, ctx_rep, ovf_list,
-                                          ovf_list + TILED_MAX_T);
+    tally_compact_body<DO_KMER, LDS_KMER, 1, PLAN_ONCE>(P, kernarg, stage, sheet, table, toffs, lds_kmer, lds_delta, refs_lds, ctx_rep, ovf_list,
+                                                        ovf_list + TILED_MAX_T);
+}
+
+// diagnostics only (PSSBAM_COMPACT_DECODE_TWICE): the same kernel with the header decode + filters done twice per lane
+__global__ void __launch_bounds__(TILED_THREADS) tally_compact_decode_twice(const TallyParams P) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t stage[];
+    __shared__ __attribute__((aligned(16))) uint8_t sheet[TILED_MAX_T * 32u];
+    __shared__ uint32_t table[COMPACT_TABLE_WORDS];
+    __shared__ uint32_t toffs[2u * (TILED_MAX_T + 4u)];
+    __shared__ uint32_t lds_kmer[1u];
+    __shared__ int32_t lds_delta[ST_USED];
+    __shared__ uint4 refs_lds[REF_LDS_ENTRIES + 1];
+    __shared__ uint32_t ctx_rep[CTX_WORDS];
+    __shared__ uint32_t ovf_list[TILED_MAX_T + 1];
+    const TallyParams *kernarg = (const TallyParams *)__builtin_amdgcn_kernarg_segment_ptr();
+    tally_compact_body<false, false, 2>(P, kernarg, stage, sheet, table, toffs, lds_kmer, lds_delta, refs_lds, ctx_rep, ovf_list,
+                                        ovf_list + TILED_MAX_T);
 }
 
 // Sums the per-workgroup partials of one tally_tiled launch into the u64 counter block.
