@@ -91,7 +91,7 @@ static bool wave_inflate_wanted() {
 }
 
 // ISIZE + CRC-32 of every inflated block against its trailer (bgzf_crc_kernel: a block per wave)
-static int launch_crc(hipStream_t st, pssbam_bgzf_block *d_blocks, uint32_t n_blocks, void *d_out) {
+static int launch_crc(hipStream_t st, pssbam_bgzf_block *d_blocks, uint32_t n_blocks, void *d_out, bool beside_inflate = false) {
     int dev = 0, n_cu = 0;
     HIP_TRY(hipGetDevice(&dev));
     HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
@@ -100,11 +100,16 @@ static int launch_crc(hipStream_t st, pssbam_bgzf_block *d_blocks, uint32_t n_bl
     if (rc) return rc;
     static bool crc_attr_set[64] = {false};
     if (!crc_attr_set[dev & 63]) {
-        HIP_TRY(hipFuncSetAttribute((const void *)pssbam::bgzf_crc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pssbam::CRC_LDS_BYTES));
+        HIP_TRY(hipFuncSetAttribute((const void *)pssbam::bgzf_crc_kernel<pssbam::CRC_REP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pssbam::CRC_LDS_BYTES));
         crc_attr_set[dev & 63] = true;
     }
-    const uint32_t cgrid = std::min<uint32_t>((n_blocks + 15) / 16, (uint32_t)n_cu);   // one 16-wave workgroup per CU, a block per wave
-    hipLaunchKernelGGL(pssbam::bgzf_crc_kernel, dim3(cgrid), dim3(1024), pssbam::CRC_LDS_BYTES, st, (const uint8_t *)d_out, (pssbam::BgzfBlock *)d_blocks, n_blocks, xpow);
+    if (beside_inflate) {   // four waves and 16 KiB of tables per workgroup: fits a CU that runs the inflate kernel
+        const uint32_t cgrid = std::min<uint32_t>((n_blocks + 3) / 4, (uint32_t)n_cu);
+        hipLaunchKernelGGL(pssbam::bgzf_crc_kernel<4u>, dim3(cgrid), dim3(256), 4u * 256u * 4u * 4u, st, (const uint8_t *)d_out, (pssbam::BgzfBlock *)d_blocks, n_blocks, xpow);
+    } else {
+        const uint32_t cgrid = std::min<uint32_t>((n_blocks + 15) / 16, (uint32_t)n_cu);   // one 16-wave workgroup per CU, a block per wave
+        hipLaunchKernelGGL(pssbam::bgzf_crc_kernel<pssbam::CRC_REP>, dim3(cgrid), dim3(1024), pssbam::CRC_LDS_BYTES, st, (const uint8_t *)d_out, (pssbam::BgzfBlock *)d_blocks, n_blocks, xpow);
+    }
     HIP_TRY(hipGetLastError());
     return PSSBAM_OK;
 }
@@ -592,7 +597,7 @@ static int feed_flush(pssbam_engine *e) {
                            s.d_out, (uint64_t)FEED_GAP, s.d_chain);
     }
     if (!getenv("PSSBAM_NO_CRC")) {
-        rc = launch_crc(e->stream, (pssbam_bgzf_block *)s.d_blocks, (uint32_t)nb, s.d_out);
+        rc = launch_crc(e->stream, (pssbam_bgzf_block *)s.d_blocks, (uint32_t)nb, s.d_out, is != e->stream && !getenv("PSSBAM_FEED_BIG_CRC"));
         if (rc) return rc;
     }
     // the record chain of the whole super-batch: per-block pieces, linked and checked

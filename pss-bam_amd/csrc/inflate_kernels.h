@@ -907,22 +907,26 @@ __device__ __forceinline__ uint32_t gf2_mul(uint32_t a, uint32_t b) {
 // x^(8 * 1024) from a 64-entry table -- and XORed together.
 constexpr uint32_t CRC_REP = 32;   // copies of every table entry, one per LDS bank
 constexpr uint32_t CRC_LDS_BYTES = 4u * 256u * CRC_REP * 4u;   // 128 KiB: one workgroup of 16 waves per CU
-__global__ void __launch_bounds__(1024) bgzf_crc_kernel(const uint8_t *out, BgzfBlock *blocks, uint32_t n_blocks,
+// REP = 32: the kernel on its own (16 waves per CU, conflict-free tables).  REP = 4: 16 KiB of tables, four waves -- slower
+// by itself, but it fits a CU beside the four workgroups of the inflate kernel (133 KB of the 160), for a feed whose next
+// inflate launch runs while this super-batch is checked (PSSBAM_FEED_INFLATE_STREAMS=2).
+template <uint32_t REP>
+__global__ void __launch_bounds__(REP >= 32u ? 1024 : 256) bgzf_crc_kernel(const uint8_t *out, BgzfBlock *blocks, uint32_t n_blocks,
                                                         const uint32_t *xpow_kib /* [64]: x^(8*1024*k) mod P */) {
     // slicing-by-4 tables, every entry replicated 32 times side by side: lane l reads copy l % 32, i.e. ALWAYS
     // bank l % 32 -- the random table indices of a wave's 64 lanes no longer collide (a single copy of the
     // tables had 67 % of the LDS cycles lost to bank conflicts: profiles/r02_inflate_prof_100M_5waves.txt)
-    extern __shared__ uint32_t crc_tab[];   // [4][256][CRC_REP]
-    for (uint32_t i = threadIdx.x; i < 4u * 256u * CRC_REP; i += blockDim.x) {
-        const uint32_t t = i / (256u * CRC_REP), v = (i / CRC_REP) & 255u;
+    extern __shared__ uint32_t crc_tab[];   // [4][256][REP]
+    for (uint32_t i = threadIdx.x; i < 4u * 256u * REP; i += blockDim.x) {
+        const uint32_t t = i / (256u * REP), v = (i / REP) & 255u;
         uint32_t c = v;   // CRC register after byte v followed by t zero bytes
         for (uint32_t k = 0; k < 8u * (t + 1u); k++) c = (c >> 1) ^ ((c & 1u) ? CRC_POLY : 0u);
         crc_tab[i] = c;
     }
     __syncthreads();
-    const uint32_t rep = threadIdx.x & (CRC_REP - 1u);
-    const uint32_t *tab0 = crc_tab + rep, *tab1 = tab0 + 256u * CRC_REP, *tab2 = tab1 + 256u * CRC_REP, *tab3 = tab2 + 256u * CRC_REP;
-#define TAB(t, v) (t)[(v) * CRC_REP]
+    const uint32_t rep = threadIdx.x & (REP - 1u);
+    const uint32_t *tab0 = crc_tab + rep, *tab1 = tab0 + 256u * REP, *tab2 = tab1 + 256u * REP, *tab3 = tab2 + 256u * REP;
+#define TAB(t, v) (t)[(v) * REP]
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
     for (uint32_t bi = blockIdx.x * waves + wave; bi < n_blocks; bi += gridDim.x * waves) {
         const BgzfBlock b = blocks[bi];

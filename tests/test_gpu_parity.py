@@ -355,6 +355,32 @@ def test_compact_tiled_switch_at_sixteen(pkg, oracle, tmp_path, monkeypatch, reg
         oracle.free_genome(g)
 
 
+@pytest.mark.parametrize("seed", [41, 42])
+def test_compact_plan_once_form(pkg, oracle, tmp_path, monkeypatch, seed):
+    """tally_compact's switchable form that decodes + filters in ONE lane per read and hands the plan to the pair through
+    LDS (PSSBAM_COMPACT_PLAN_ONCE=1; measured slower, off by default -- profiles/r03_ab_plan_once.txt): same tables and
+    status tallies as the oracle, fragkon's k-mer tables included, tiles that are not full included (chunks)"""
+    contigs, refs, recs = tl.fuzz_dataset(seed, 4000)
+    fa, sam = tmp_path / "g.fa", tmp_path / "a.sam"
+    tl.write_fasta(fa, contigs)
+    tl.write_sam(sam, refs, recs)
+    raw = tl.raw_records(refs, recs)
+    g = oracle.load_genome(fa)
+    monkeypatch.setenv("PSSBAM_COMPACT_PLAN_ONCE", "1")
+    try:
+        for po in (tl.PssOpts(region_len=15), tl.PssOpts(region_len=9, min_mq=10, up_ctx="CT", down_ctx="AG")):
+            wf, wr, st = oracle.pss(g, sam, po)
+            for chunks in (1, 3):
+                got = _engine_tables(pkg, contigs, refs, raw, pss=_pss_dict(po), kernel=pkg.KERNEL_TILED, chunks=chunks)
+                _check_pss(got, wf, wr, st)
+        ko = tl.FkOpts(klen=4)
+        w5, w3, _ = oracle.fragkon(g, sam, ko)
+        got = _engine_tables(pkg, contigs, refs, raw, pss=_pss_dict(tl.PssOpts(region_len=15)), kmer=_fk_dict(ko), kernel=pkg.KERNEL_TILED, chunks=2)
+        assert np.array_equal(got.k5, w5) and np.array_equal(got.k3, w3)
+    finally:
+        oracle.free_genome(g)
+
+
 def test_read_group_behind_large_aux_arrays(pkg, oracle, tmp_path):
     """B arrays of thousands of elements (every sub-type), H strings and floats in front of and behind RG:Z: the -R
     walk of the device decoders must step over all of them by type (reference: `samtools view -r`,
