@@ -517,6 +517,7 @@ static int feed_flush(pssbam_engine *e) {
     if (s.blocks.empty()) return PSSBAM_OK;
     int rc;
     const double t_flush0 = feed_now();
+    if (e->feed_t_first_flush < 0) e->feed_t_first_flush = t_flush0 - e->feed_t0;
     struct FlushTimer { pssbam_engine *e; double t0; ~FlushTimer() { e->feed_t_flush += feed_now() - t0; } } flush_timer{e, t_flush0};
     const size_t nb = s.blocks.size();
     if (nb > 0xFFFFFFF0ull) return fail(PSSBAM_EINVAL, "too many BGZF blocks in one super-batch");
@@ -714,6 +715,7 @@ static int feed_append(pssbam_engine *e, const uint8_t *comp, const pssbam_bgzf_
 // the feed's per-engine device words and targets, made at the first use of the feed
 static int feed_state_init(pssbam_engine *e) {
     if (e->d_feed_flags) return PSSBAM_OK;
+    e->feed_t0 = feed_now();
     if (getenv("PSSBAM_FEED_SUPER_BYTES")) e->feed_out_target = std::max<uint64_t>(1ull << 20, strtoull(getenv("PSSBAM_FEED_SUPER_BYTES"), nullptr, 10));
     // the inflate kernel keeps INF_WAVES_PER_CU waves x 64 lanes per CU busy, a block per lane, and blocks take about the
     // same time: a super-batch of a whole number of "rounds" of blocks wastes no partial round
@@ -962,10 +964,10 @@ extern "C" int pssbam_engine_feed_status(pssbam_engine *e, uint32_t *flags, doub
     }
     if (getenv("PSSBAM_STATS"))
         fprintf(stderr, "[pssbam] engine feed: %llu super-batches (%llu cut short because the device had run dry; their blocks filled %.0f %% of the lanes of the inflate launches) in %zu slots (%llu allocated here), %llu tally launches put off until the genome was set; "
-                        "buffer allocation %.3f, waiting for a busy slot %.3f, flush (block table + launches) %.3f s\n",
+                        "buffer allocation %.3f, waiting for a busy slot %.3f, flush (block table + launches) %.3f s; first launch %.3f s after the first block came\n",
                 (unsigned long long)e->flush_seq, (unsigned long long)e->feed_early_flushes,
                 e->feed_lanes_launched ? 100.0 * (double)e->feed_blocks_launched / (double)e->feed_lanes_launched : 0.0, e->feed.size(), (unsigned long long)e->feed_slots_allocated, (unsigned long long)e->feed_deferred_launches,
-                e->feed_t_alloc, e->feed_t_wait_busy, e->feed_t_flush);
+                e->feed_t_alloc, e->feed_t_wait_busy, e->feed_t_flush, e->feed_t_first_flush);
     if (flags) *flags = f;
     if (inflate_ms) *inflate_ms = e->inflate_ms;
     if (inflated_bytes) *inflated_bytes = e->inflated_bytes;

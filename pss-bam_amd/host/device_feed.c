@@ -310,6 +310,8 @@ int run_device_feed(pssbam_engine *const *eng, int n_gpus, const char *path, siz
     } while (0)
 
     double t_wait_load = 0, t_wait_copy = 0, t_scan = 0, t_submit = 0, t_gate = 0;
+    const double t_entry = mono_s();
+    double t_first_submit = -1, t_first_submit_dur = 0;   /* when the first chunk went to an engine, and how long that call took */
     uint64_t n_submits_ahead = 0;   /* submits that went in before the genome was set */
     long n_prescanned = 0;
     size_t pos = 0;                /* file offset of the next BGZF block */
@@ -396,6 +398,7 @@ int run_device_feed(pssbam_engine *const *eng, int n_gpus, const char *path, siz
                     goto done;
                 }
                 t_submit += mono_s() - tsub;
+                if (t_first_submit < 0) { t_first_submit = tsub - t_entry; t_first_submit_dur = mono_s() - tsub; }
                 if (!gate_open) n_submits_ahead++;
                 skip = 0;
                 n_submits++;
@@ -455,8 +458,8 @@ int run_device_feed(pssbam_engine *const *eng, int n_gpus, const char *path, siz
     if (verbose)
         fprintf(stderr, "[pssbam] device feed, this thread: waiting for loaders %.3f, block-header walk %.3f (%ld of %ld windows walked by "
                         "their loader), submit (incl. waiting for a free slot) %.3f, waiting for copies %.3f, waiting for the genome %.3f s "
-                        "(%llu of the submits went in ahead of it)\n", t_wait_load, t_scan,
-                n_prescanned, L->n_chunks, t_submit, t_wait_copy, t_gate, (unsigned long long)n_submits_ahead);
+                        "(%llu of the submits went in ahead of it); first submit %.3f s after the feed began (the call took %.3f s)\n", t_wait_load, t_scan,
+                n_prescanned, L->n_chunks, t_submit, t_wait_copy, t_gate, (unsigned long long)n_submits_ahead, t_first_submit, t_first_submit_dur);
     rc = 0;
 done:
     if (rc) {   /* nothing may still read the staging slots */

@@ -95,6 +95,13 @@ static void early_engines_done(void)
 
 static int feed_run(int n_gpus);
 
+static void *pin_main(void *arg)
+{
+    (void)arg;
+    device_feed_prefetch_pin();
+    return NULL;
+}
+
 static void *reserve_main(void *arg)
 {
     (void)pssbam_feed_reserve((int)(intptr_t)arg); /* best effort */
@@ -129,6 +136,10 @@ static void early_feed_main(void)
             pthread_t th;
             if (pthread_create(&th, NULL, reserve_main, (void *)(intptr_t)g) == 0) pthread_detach(th);
         }
+    /* the loader's staging slots (already being filled) are page-locked beside the engine set-up too: 320 MB take ~30 ms,
+     * which used to sit between "engines up" and the first block going out */
+    pthread_t pin_th;
+    const int pin_started = pthread_create(&pin_th, NULL, pin_main, NULL) == 0;
     const bam_header *h = bam_reader_header(early_rd);
     /* one engine per GPU, all created at once: a device's first touch (context, queues, code objects) takes ~0.08 s, and
      * eight of them one after the other would cost more than the whole command does on one GPU */
@@ -152,6 +163,7 @@ static void early_feed_main(void)
             EF.failed = 1;
             EF.n_gpus = n;   /* (whatever was created is destroyed with the rest: NULL entries are skipped) */
             early_engines_done();
+            if (pin_started) pthread_join(pin_th, NULL);
             return;
         }
         EF.n_gpus = g + 1;
@@ -169,6 +181,7 @@ static void early_feed_main(void)
             for (int g = 0; g < n; g++) (void)pssbam_engine_hint_records(EF.eng[g], r0, nb0);
         if (slot0 >= 0) bam_reader_release(early_rd, slot0);
     }
+    if (pin_started) pthread_join(pin_th, NULL);
     const feed_gate gate = {early_gate, NULL};
     EF.feed_rc = run_device_feed(EF.eng, n, early_path, bam_reader_header_bytes(early_rd), feed_run(n), getenv("PSSBAM_STATS") != NULL, &EF.dfs, &gate);
     EF.fed = 1;
