@@ -220,6 +220,7 @@ struct pssbam_engine {
     hipEvent_t handoff_ev = nullptr;   // recorded on this engine's stream behind the hand-off of its own tail
     uint64_t feed_out_target = FEED_OUT_TARGET, feed_comp_cap = FEED_COMP_CAP;   // per super-batch
     double feed_t_alloc = 0, feed_t_wait_busy = 0, feed_t_flush = 0;   // host seconds inside the feed (PSSBAM_STATS)
+    double feed_t0 = 0, feed_t_first_flush = -1;                        // host clock of the first submit_bgzf; first flush, seconds after it
     uint64_t feed_slots_allocated = 0, feed_deferred_launches = 0, feed_early_flushes = 0;
     uint64_t feed_blocks_launched = 0, feed_lanes_launched = 0;   // blocks inflated / lanes their launches occupied (whole rounds of the kernel's grid)
     uint64_t feed_idle_min_blocks = 8192;   // a super-batch of at least so many blocks is flushed early when the device has run dry ($PSSBAM_FEED_IDLE_BLOCKS, 0 = never)
