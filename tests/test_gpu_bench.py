@@ -58,7 +58,7 @@ def test_bench_e2e_leg_small():
     e = d["e2e"]
     assert "error" not in e, e
     assert e["reads"] == 3_000_000 and e["tables_check"].startswith("tables identical")
-    assert e["wall_s"] > 0 and e["fasta_load_s"] is not None and len(e["wall_s_runs"]) == 3
+    assert e["wall_s"] > 0 and e["fasta_load_s"] is not None and len(e["wall_s_runs"]) == 5
     assert e["host_inflate_run"]["tables_identical"]
     assert 0 < e["gpu_busy_s"] < e["wall_s_foreground_exit"] and e["wall_s_foreground_exit"] > 0 and e["early_feed"]
     assert "error" not in e["level0"] and e["level0"]["reads"] == 3_000_000 and e["level0"]["bam_bytes"] > 5 * e["bam_bytes"]
