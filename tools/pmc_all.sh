@@ -7,4 +7,4 @@ python3 tools/pmc_profile.py C3_shuffled -- --config C3 --unsorted --reads 10000
 python3 tools/pmc_profile.py C4 -- --config C4 --steps 3 --warmup 1 > gpurun_out/pmc_C4.txt 2>&1
 python3 tools/pmc_profile.py C5 -- --config C5 --reads 100000000 --steps 3 --warmup 1 > gpurun_out/pmc_C5.txt 2>&1
 python3 tools/pmc_profile.py C1 -- --config C1 --reads 20000000 --steps 3 --warmup 1 > gpurun_out/pmc_C1.txt 2>&1
-tail -4 gpurun_out/pmc_*.txt
+for f in gpurun_out/pmc_*.txt; do tail -n 4 "$f"; done
