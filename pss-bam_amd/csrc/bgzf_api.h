@@ -609,7 +609,7 @@ static int feed_flush(pssbam_engine *e) {
         const pssbam::BgzfBlock *blk = (const pssbam::BgzfBlock *)s.d_blocks;
         hipLaunchKernelGGL(pssbam::bgzf_chain_spec, dim3(grid), dim3(256), 0, e->stream, (const uint8_t *)s.d_out, blk, n, data_end,
                            (const uint64_t *)s.d_chain, n_ref, s.d_a, s.d_n, s.d_e, s.d_last, e->d_feed_flags, s.d_chain + 2);
-        hipLaunchKernelGGL(pssbam::bgzf_chain_suffix, dim3(1), dim3(1024), 0, e->stream, (const uint64_t *)s.d_a, n, s.d_nexta);
+        hipLaunchKernelGGL(pssbam::bgzf_chain_suffix, dim3(1), dim3(1024), 0, e->stream, (const uint64_t *)s.d_a, n, s.d_nexta, (const uint64_t *)nullptr);
         hipLaunchKernelGGL(pssbam::bgzf_chain_verify<false>, dim3(grid), dim3(256), 0, e->stream, (const uint8_t *)s.d_out, (const uint32_t *)s.d_n, (const uint64_t *)s.d_e,
                            (const uint64_t *)s.d_last, (const uint64_t *)s.d_nexta, n, data_end, (const uint64_t *)s.d_chain, s.d_counts,
                            s.d_chain + 1, e->d_feed_flags, s.d_chain + 2);
@@ -619,7 +619,7 @@ static int feed_flush(pssbam_engine *e) {
         const int repair = rv ? atoi(rv) : 1;
         hipLaunchKernelGGL(pssbam::bgzf_chain_repair, dim3(1), dim3(64), 0, e->stream, (const uint8_t *)s.d_out, blk, n, data_end, (const uint64_t *)s.d_chain,
                            n_ref, s.d_a, s.d_n, s.d_e, s.d_last, (const uint64_t *)s.d_nexta, e->d_feed_flags, s.d_chain + 2, repair);
-        hipLaunchKernelGGL(pssbam::bgzf_chain_suffix, dim3(1), dim3(1024), 0, e->stream, (const uint64_t *)s.d_a, n, s.d_nexta);
+        hipLaunchKernelGGL(pssbam::bgzf_chain_suffix, dim3(1), dim3(1024), 0, e->stream, (const uint64_t *)s.d_a, n, s.d_nexta, (const uint64_t *)(s.d_chain + 3));
         hipLaunchKernelGGL(pssbam::bgzf_chain_verify<true>, dim3(grid), dim3(256), 0, e->stream, (const uint8_t *)s.d_out, (const uint32_t *)s.d_n, (const uint64_t *)s.d_e,
                            (const uint64_t *)s.d_last, (const uint64_t *)s.d_nexta, n, data_end, (const uint64_t *)s.d_chain, s.d_counts,
                            s.d_chain + 1, e->d_feed_flags, s.d_chain + 2);

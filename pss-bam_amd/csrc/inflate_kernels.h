@@ -1088,7 +1088,8 @@ __global__ void __launch_bounds__(256) bgzf_chain_spec(const uint8_t *out, const
 }
 
 // nexta[b] = the first record start at or after block b (suffix minimum of a[]; a[] grows with b), nexta[n] = NONE
-__global__ void __launch_bounds__(1024) bgzf_chain_suffix(const uint64_t *a, uint32_t n, uint64_t *nexta) {
+__global__ void __launch_bounds__(1024) bgzf_chain_suffix(const uint64_t *a, uint32_t n, uint64_t *nexta, const uint64_t *only_if = nullptr) {
+    if (only_if && !*only_if) return;   // (the pass behind bgzf_chain_repair: nothing was repaired)
     __shared__ uint64_t part[1024];
     const uint32_t t = threadIdx.x, per = (n + 1023u) / 1024u;
     const uint32_t lo = min(n, t * per), hi = min(n, lo + per);
