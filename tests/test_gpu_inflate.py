@@ -421,9 +421,13 @@ def test_feed_repairs_a_false_record_start(pkg, tmp_path, monkeypatch, trailer):
         assert a == b, (got.stats, want.stats)
 
 
-def test_feed_flags_damage_and_truncation(pkg, tmp_path):
+@pytest.mark.parametrize("inflate_streams", ["1", "2"])
+def test_feed_flags_damage_and_truncation(pkg, tmp_path, monkeypatch, inflate_streams):
     """a damaged block raises PSSBAM_FEED_BAD_BLOCK; a stream that ends inside a record raises
-    PSSBAM_FEED_TRUNCATED"""
+    PSSBAM_FEED_TRUNCATED -- also with the inflate launches on streams of their own and the 16 KiB-table form of the CRC
+    kernel behind them (PSSBAM_FEED_INFLATE_STREAMS=2: a switch that is off by default and must not rot)"""
+    monkeypatch.setenv("PSSBAM_FEED_INFLATE_STREAMS", inflate_streams)
+    monkeypatch.setenv("PSSBAM_FEED_SUPER_BYTES", str(1 << 20))   # several super-batches: the streams do take turns
     contigs, refs, recs = tl.fuzz_dataset(31, 3000)
     bam = tmp_path / "a.bam"
     hb = tl.write_bam_aligned(bam, refs, recs, level=1, rng=np.random.default_rng(3))
@@ -493,6 +497,9 @@ def test_cli_device_feed_and_fallback(pkg, oracle, tmp_path):
     assert re.search(r"device feed: (\d+) submits", err) and "host reader" not in err
     err = run_pss(aligned, {"PSSBAM_DEVICE_INFLATE": "0"})
     assert "device feed" not in err
+    err = run_pss(ragged, {"PSSBAM_FEED_INFLATE_STREAMS": "2", "PSSBAM_FEED_SUPER_BYTES": str(4 << 20), "PSSBAM_FEED_BATCH_BYTES": str(1 << 20),
+                           "PSSBAM_CHUNK_BYTES": str(1 << 20)})   # the off-by-default two-stream form of the feed, many super-batches
+    assert re.search(r"device feed: (\d+) submits", err) and "host reader" not in err
     # two engines are dealt alternating runs of the file: the record a run ends in is handed to the engine that
     # gets the next run (pssbam_engine_feed_handoff) -- a file in htsjdk's layout stays on the device feed
     err = run_pss(ragged, {"PSSBAM_CHUNK_BYTES": str(1 << 20), "PSSBAM_NGPU": "2", "PSSBAM_OVERSUBSCRIBE": "1",
