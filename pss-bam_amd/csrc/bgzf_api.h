@@ -107,8 +107,10 @@ static int launch_crc(hipStream_t st, pssbam_bgzf_block *d_blocks, uint32_t n_bl
         const uint32_t cgrid = std::min<uint32_t>((n_blocks + 3) / 4, (uint32_t)n_cu);
         hipLaunchKernelGGL(pssbam::bgzf_crc_kernel<4u>, dim3(cgrid), dim3(256), 4u * 256u * 4u * 4u, st, (const uint8_t *)d_out, (pssbam::BgzfBlock *)d_blocks, n_blocks, xpow);
     } else {
-        const uint32_t cgrid = std::min<uint32_t>((n_blocks + 15) / 16, (uint32_t)n_cu);   // one 16-wave workgroup per CU, a block per wave
-        hipLaunchKernelGGL(pssbam::bgzf_crc_kernel<pssbam::CRC_REP>, dim3(cgrid), dim3(1024), pssbam::CRC_LDS_BYTES, st, (const uint8_t *)d_out, (pssbam::BgzfBlock *)d_blocks, n_blocks, xpow);
+        // one workgroup per CU, a block per wave (PSSBAM_CRC_WAVES: experiments with fewer lines in flight)
+        static const uint32_t crc_waves = getenv("PSSBAM_CRC_WAVES") ? (uint32_t)std::min(16, std::max(1, atoi(getenv("PSSBAM_CRC_WAVES")))) : 16u;
+        const uint32_t cgrid = std::min<uint32_t>((n_blocks + crc_waves - 1) / crc_waves, (uint32_t)n_cu);
+        hipLaunchKernelGGL(pssbam::bgzf_crc_kernel<pssbam::CRC_REP>, dim3(cgrid), dim3(64 * crc_waves), pssbam::CRC_LDS_BYTES, st, (const uint8_t *)d_out, (pssbam::BgzfBlock *)d_blocks, n_blocks, xpow);
     }
     HIP_TRY(hipGetLastError());
     return PSSBAM_OK;
