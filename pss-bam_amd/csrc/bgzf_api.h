@@ -69,6 +69,36 @@ int ensure_xpow(int dev, uint32_t **out) {
     *out = g_xpow_dev[dev];
     return PSSBAM_OK;
 }
+// per device, for bgzf_crc_lines_kernel: x^(8*16*k) mod P (k = 0..63) and the four byte tables of "the register moved on by
+// 1024 zero bytes" (Z_j[v] = (v << 8j) * x^8192 mod P)
+uint32_t *g_crc2_dev[64] = {nullptr};   // [64 + 4 * 256]
+int ensure_crc2_tabs(int dev, uint32_t **xpow16, uint32_t **ztab) {
+    if (dev < 0 || dev >= 64) return fail(PSSBAM_EINVAL, "device %d out of range", dev);
+    if (!g_crc2_dev[dev]) {
+        std::vector<uint32_t> h(64 + 4 * 256);
+        uint32_t x16 = 0x80000000u;   // x^0
+        for (int i = 0; i < 8 * 16; i++) x16 = (x16 >> 1) ^ ((x16 & 1u) ? 0xEDB88320u : 0u);
+        h[0] = 0x80000000u;
+        for (int k = 1; k < 64; k++) h[k] = host_gf2_mul(h[k - 1], x16);
+        uint32_t t0[256];   // the byte table: the register after one more byte
+        for (uint32_t v = 0; v < 256; v++) {
+            uint32_t c = v;
+            for (int k = 0; k < 8; k++) c = (c >> 1) ^ ((c & 1u) ? 0xEDB88320u : 0u);
+            t0[v] = c;
+        }
+        for (uint32_t j = 0; j < 4; j++)
+            for (uint32_t v = 0; v < 256; v++) {
+                uint32_t c = v << (8 * j);
+                for (int n = 0; n < 1024; n++) c = t0[c & 0xFFu] ^ (c >> 8);
+                h[64 + j * 256 + v] = c;
+            }
+        HIP_TRY(hipMalloc(&g_crc2_dev[dev], h.size() * sizeof(uint32_t)));
+        HIP_TRY(hipMemcpy(g_crc2_dev[dev], h.data(), h.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
+    *xpow16 = g_crc2_dev[dev];
+    *ztab = g_crc2_dev[dev] + 64;
+    return PSSBAM_OK;
+}
 }  // namespace
 
 static_assert(sizeof(pssbam_bgzf_block) == sizeof(pssbam::BgzfBlock), "public and device block descriptors must match");
@@ -102,6 +132,22 @@ static int launch_crc(hipStream_t st, pssbam_bgzf_block *d_blocks, uint32_t n_bl
     if (!crc_attr_set[dev & 63]) {
         HIP_TRY(hipFuncSetAttribute((const void *)pssbam::bgzf_crc_kernel<pssbam::CRC_REP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pssbam::CRC_LDS_BYTES));
         crc_attr_set[dev & 63] = true;
+    }
+    static const int crc_form = getenv("PSSBAM_CRC_FORM") ? atoi(getenv("PSSBAM_CRC_FORM")) : 1;   // 1: whole lines per request (bgzf_crc_lines_kernel), 0: a 1 KiB chunk per lane
+    if (crc_form == 1 && !beside_inflate) {
+        uint32_t *xpow16 = nullptr, *ztab = nullptr;
+        rc = ensure_crc2_tabs(dev, &xpow16, &ztab);
+        if (rc) return rc;
+        static bool crc2_attr_set[64] = {false};
+        if (!crc2_attr_set[dev & 63]) {
+            HIP_TRY(hipFuncSetAttribute((const void *)pssbam::bgzf_crc_lines_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pssbam::CRC2_LDS_BYTES));
+            crc2_attr_set[dev & 63] = true;
+        }
+        const uint32_t cgrid = std::min<uint32_t>((n_blocks + 15) / 16, (uint32_t)n_cu);
+        hipLaunchKernelGGL(pssbam::bgzf_crc_lines_kernel, dim3(cgrid), dim3(1024), pssbam::CRC2_LDS_BYTES, st, (const uint8_t *)d_out, (pssbam::BgzfBlock *)d_blocks, n_blocks,
+                           (const uint32_t *)xpow16, (const uint32_t *)ztab);
+        HIP_TRY(hipGetLastError());
+        return PSSBAM_OK;
     }
     if (beside_inflate) {   // four waves and 16 KiB of tables per workgroup: fits a CU that runs the inflate kernel
         const uint32_t cgrid = std::min<uint32_t>((n_blocks + 3) / 4, (uint32_t)n_cu);

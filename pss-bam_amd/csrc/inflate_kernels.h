@@ -979,6 +979,92 @@ __global__ void __launch_bounds__(REP >= 32u ? 1024 : 256) bgzf_crc_kernel(const
 #undef TAB
 }
 
+// The same check with WHOLE LINES per request (round 3, profiles/r03_crc_pmc.txt: the kernel above fetches every 128-byte
+// line from the fabric twice -- its lanes sit 1 KiB apart and ask for their line 16 bytes at a time -- and sits on the
+// HBM ceiling at 2x the data).  Here the lanes of a wave read ADJACENT 16-byte pieces: lane l owns pieces l, l + 64,
+// l + 128, ... of the block, one wave-instruction fetches 1 KiB of consecutive bytes.  CRC is linear, so a lane keeps
+//     acc <- acc * x^(8*1024)  +  R(piece)        R = the register after the piece's 16 bytes from state 0
+// (Horner over its pieces, which lie 1 KiB apart; the multiplication by the fixed x^8192 is four more table look-ups,
+// tables Z0..Z3, worked out on the host), and at the end its sum moves to the end of the full pieces by x^(128 * pieces
+// behind it) -- a 64-entry power table -- and the lanes' sums are XORed.  Bytes in front of the first 16-byte aligned
+// piece and behind the last full one (<= 15 each) go through the byte table in lane 0.  Eight tables, sixteen copies of
+// every entry side by side (lane l reads copy l % 16): 128 KiB, one 16-wave workgroup per CU as before.
+constexpr uint32_t CRC2_REP = 16;
+constexpr uint32_t CRC2_LDS_BYTES = 8u * 256u * CRC2_REP * 4u;
+__global__ void __launch_bounds__(1024) bgzf_crc_lines_kernel(const uint8_t *out, BgzfBlock *blocks, uint32_t n_blocks,
+                                                              const uint32_t *xpow16 /* [64]: x^(8*16*k) mod P */,
+                                                              const uint32_t *ztab /* [4][256]: the register moved on by 1024 zero bytes */) {
+    extern __shared__ uint32_t crc2_tab[];   // [8][256][CRC2_REP]
+    for (uint32_t i = threadIdx.x; i < 8u * 256u * CRC2_REP; i += blockDim.x) {
+        const uint32_t t = i / (256u * CRC2_REP), v = (i / CRC2_REP) & 255u;
+        uint32_t c;
+        if (t < 4u) {
+            c = v;   // CRC register after byte v followed by t zero bytes
+            for (uint32_t k = 0; k < 8u * (t + 1u); k++) c = (c >> 1) ^ ((c & 1u) ? CRC_POLY : 0u);
+        } else c = ztab[(t - 4u) * 256u + v];
+        crc2_tab[i] = c;
+    }
+    __syncthreads();
+    const uint32_t rep = threadIdx.x & (CRC2_REP - 1u);
+    const uint32_t *tab0 = crc2_tab + rep, *tab1 = tab0 + 256u * CRC2_REP, *tab2 = tab1 + 256u * CRC2_REP, *tab3 = tab2 + 256u * CRC2_REP;
+    const uint32_t *z0 = tab3 + 256u * CRC2_REP, *z1 = z0 + 256u * CRC2_REP, *z2 = z1 + 256u * CRC2_REP, *z3 = z2 + 256u * CRC2_REP;
+#define TAB2(t, v) (t)[(v) * CRC2_REP]
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
+    for (uint32_t bi = blockIdx.x * waves + wave; bi < n_blocks; bi += gridDim.x * waves) {
+        const BgzfBlock b = blocks[bi];
+        if (b.status != INF_OK) continue;
+        const uint32_t T = b.isize;
+        const uint8_t *p = out + b.out_off;
+        const uint32_t head = min((16u - (uint32_t)((uintptr_t)p & 15u)) & 15u, T);   // bytes in front of the first aligned piece
+        const uint32_t n_full = (T - head) >> 4, tail = (T - head) & 15u;
+        const uint4 *pieces = (const uint4 *)(p + head);
+        // lane 0 starts the block: 0xFFFFFFFF through the head bytes is the state its first piece starts from
+        uint32_t s0 = 0u;
+        if (lane == 0u) {
+            s0 = 0xFFFFFFFFu;
+            for (uint32_t i = 0; i < head; i++) s0 = TAB2(tab0, (s0 ^ p[i]) & 0xFFu) ^ (s0 >> 8);
+        }
+        uint32_t acc = 0u, n_mine = 0u;
+        for (uint32_t i0 = lane; i0 < n_full; i0 += 8u * 64u) {
+            uint4 q[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (i0 + 64u * (uint32_t)u < n_full) q[u] = pieces[i0 + 64u * (uint32_t)u];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                if (i0 + 64u * (uint32_t)u < n_full) {
+                    const uint32_t d[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
+                    uint32_t r = n_mine ? 0u : s0;   // (s0 is 0 in every lane but the block's first)
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const uint32_t w = d[k] ^ r;
+                        r = TAB2(tab3, w & 0xFFu) ^ TAB2(tab2, (w >> 8) & 0xFFu) ^ TAB2(tab1, (w >> 16) & 0xFFu) ^ TAB2(tab0, w >> 24);
+                    }
+                    // acc * x^8192: the register moved on by the 1024 bytes between this lane's pieces
+                    const uint32_t m = TAB2(z0, acc & 0xFFu) ^ TAB2(z1, (acc >> 8) & 0xFFu) ^ TAB2(z2, (acc >> 16) & 0xFFu) ^ TAB2(z3, acc >> 24);
+                    acc = (n_mine ? m : 0u) ^ r;
+                    n_mine++;
+                }
+            }
+        }
+        // to the end of the full pieces: 16 * (pieces behind this lane's last one) bytes, 0..63 pieces
+        if (n_mine) {
+            const uint32_t last = lane + 64u * (n_mine - 1u);
+            const uint32_t behind = n_full - 1u - last;
+            if (behind) acc = gf2_mul(acc, xpow16[behind]);
+        }
+        for (int o = 32; o >= 1; o >>= 1) acc ^= (uint32_t)__shfl_xor((int)acc, o);
+        if (lane == 0u) {
+            uint32_t crc = n_full ? acc : s0;   // (no full piece: the head was everything so far)
+            const uint8_t *t8 = p + head + 16u * n_full;
+            for (uint32_t i = 0; i < tail; i++) crc = TAB2(tab0, (crc ^ t8[i]) & 0xFFu) ^ (crc >> 8);
+            const uint32_t final_crc = T ? ~crc : 0u;
+            if (final_crc != b.crc) blocks[bi].status = INF_BAD_CRC;
+        }
+    }
+#undef TAB2
+}
+
 
 // ---------------------------------------------------------------------------------------
 // record index of an inflated super-batch, on the device
