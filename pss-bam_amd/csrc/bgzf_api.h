@@ -594,8 +594,9 @@ static int feed_flush(pssbam_engine *e) {
         HIP_TRY(hipEventCreateWithFlags(&s.copies_done2, hipEventDisableTiming));
     }
     late_streams(e, false);
-    HIP_TRY(hipEventRecord(s.copies_done, e->copy_stream));
-    HIP_TRY(hipEventRecord(s.copies_done2, e->copy_stream2 ? e->copy_stream2 : e->copy_stream));
+    // (chunks that went out before the copy streams existed were copied on the engine's stream: in order with what follows)
+    HIP_TRY(hipEventRecord(s.copies_done, e->copy_stream ? e->copy_stream : e->stream));
+    HIP_TRY(hipEventRecord(s.copies_done2, e->copy_stream2 ? e->copy_stream2 : e->copy_stream ? e->copy_stream : e->stream));
     // The inflate launch can go to one of two streams of its own (PSSBAM_FEED_INFLATE_STREAMS=2: launches take turns, the head
     // of one fills the CUs the tail of the previous one leaves; CRC / index / tally stay on the engine's stream behind an
     // event).  ✗ Measured on the 200 M-read command: feed phase 0.340-0.362 s with, 0.337-0.363 s without -- the blocks of a
@@ -846,7 +847,7 @@ extern "C" int pssbam_engine_submit_bgzf(pssbam_engine *e, const void *comp, uin
         }
     }
     late_streams(e, false);
-    hipStream_t cs = (e->ticket_seq & 1u) && e->copy_stream2 ? e->copy_stream2 : e->copy_stream;
+    hipStream_t cs = (e->ticket_seq & 1u) && e->copy_stream2 ? e->copy_stream2 : e->copy_stream ? e->copy_stream : e->stream;
     uint32_t b0 = 0;
     while (b0 < n_blocks) {
         if (e->cur_feed < 0) {

@@ -163,13 +163,13 @@ struct pssbam_engine {
     hipStream_t inflate_stream[2] = {nullptr, nullptr};   // PSSBAM_FEED_INFLATE_STREAMS=2: the feed's inflate launches take turns on these (bgzf_api.h feed_flush; off by default)
     hipEvent_t feed_base_ev = nullptr;                    // time zero of the feed's kernel intervals (feed_status: their union)
     hipStream_t genome_stream = nullptr;   // genome upload + encode + pack: beside whatever the engine's stream runs
-    // A HIP stream costs 10-25 ms to create (a hardware queue each): the two that are not needed for the FIRST blocks of a
-    // feed -- the second copy stream and the genome's -- are made by a helper thread while the first blocks go out, and
-    // adopted when they are there (late_streams()).
+    // A HIP stream costs 20-30 ms to create (a hardware queue each): only the engine's own is made before create returns;
+    // the copy streams and the genome's are made by a helper thread while the first blocks go out -- those are copied on
+    // the engine's stream, in front of the kernel that reads them anyway -- and adopted when they are there (late_streams()).
     std::thread late_thread;
     std::atomic<int> late_ready{0};
     std::mutex late_mu;
-    hipStream_t late_copy2 = nullptr, late_genome = nullptr;
+    hipStream_t late_copy1 = nullptr, late_copy2 = nullptr, late_genome = nullptr;
     bool late_adopted = false;
     hipEvent_t genome_ready = nullptr;
     bool genome_wait_pending = false;      // the next tally launch makes the engine's stream wait for genome_ready
@@ -275,6 +275,7 @@ static void late_streams(pssbam_engine *e, bool wait) {
     if (e->late_adopted) return;
     if (!wait && !e->late_ready.load(std::memory_order_acquire)) return;
     if (e->late_thread.joinable()) e->late_thread.join();
+    e->copy_stream = e->late_copy1;
     e->copy_stream2 = e->late_copy2;
     e->genome_stream = e->late_genome;
     e->late_adopted = true;
@@ -329,14 +330,15 @@ extern "C" int pssbam_engine_create(const pssbam_config *cfg, pssbam_engine **ou
     e->n_cu = pr.multiProcessorCount;
     const double tc1 = tstat ? feed_now() : 0.0;
     HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
     if (getenv("PSSBAM_STREAMS_UP_FRONT")) {   // (A/B: all four streams before create returns, as in round 2)
+        HIP_TRY(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
         HIP_TRY(hipStreamCreateWithFlags(&e->copy_stream2, hipStreamNonBlocking));
         HIP_TRY(hipStreamCreateWithFlags(&e->genome_stream, hipStreamNonBlocking));
         e->late_adopted = true;
     } else {
         e->late_thread = std::thread([e, dev]() {
             if (hipSetDevice(dev) == hipSuccess) {
+                if (hipStreamCreateWithFlags(&e->late_copy1, hipStreamNonBlocking) != hipSuccess) e->late_copy1 = nullptr;
                 if (hipStreamCreateWithFlags(&e->late_copy2, hipStreamNonBlocking) != hipSuccess) e->late_copy2 = nullptr;
                 if (hipStreamCreateWithFlags(&e->late_genome, hipStreamNonBlocking) != hipSuccess) e->late_genome = nullptr;
             }
@@ -383,7 +385,7 @@ extern "C" int pssbam_engine_create(const pssbam_config *cfg, pssbam_engine **ou
     if (getenv("PSSBAM_COMPACT")) e->use_compact = env_int("PSSBAM_COMPACT") != 0;
     if (getenv("PSSBAM_COMPACT_PLAN_ONCE")) e->compact_plan_once = env_int("PSSBAM_COMPACT_PLAN_ONCE") != 0;
     if (tstat)
-        fprintf(stderr, "[pssbam] engine on device %d: device properties %.3f, 2 streams + events %.3f, counters + scratch (first allocations, first "
+        fprintf(stderr, "[pssbam] engine on device %d: device properties %.3f, its stream + events %.3f, counters + scratch (first allocations, first "
                         "enqueue) %.3f s\n", dev, tc1 - tc0, tc2 - tc1, feed_now() - tc2);
     *out = guard.release();
     return PSSBAM_OK;
@@ -1003,7 +1005,8 @@ extern "C" int pssbam_engine_submit_async(pssbam_engine *e, const void *records,
     // H2D on the copy stream so it overlaps the previous block's kernel
     // large blocks go over two copy streams (two DMA engines): one stream alone does not fill
     // the PCIe link
-    late_streams(e, false);
+    late_streams(e, true);   // (this path copies on a stream of its own from the first block on)
+    if (!e->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
     const uint64_t half = (nbytes >= (64ull << 20) && e->copy_stream2 && !getenv("PSSBAM_ONE_COPY_STREAM")) ? (nbytes / 2) & ~4095ull : 0;
     HIP_TRY(hipEventRecord(s.copy_begin, e->copy_stream));
     if (half) {
@@ -1089,7 +1092,7 @@ extern "C" int pssbam_engine_sync(pssbam_engine *e) {
         if (rc) return rc;
     }
     if (e->copy_stream2) HIP_TRY(hipStreamSynchronize(e->copy_stream2));
-    HIP_TRY(hipStreamSynchronize(e->copy_stream));
+    if (e->copy_stream) HIP_TRY(hipStreamSynchronize(e->copy_stream));
     if (e->genome_stream) HIP_TRY(hipStreamSynchronize(e->genome_stream));
     for (hipStream_t q : e->inflate_stream)
         if (q) HIP_TRY(hipStreamSynchronize(q));
